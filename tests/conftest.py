@@ -1,0 +1,47 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fi" and z[k].ndim > 0 else z[k]) for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def edm_sd():
+    from ml_conformer_generator_amd.weights import synth_edm_state_dict
+    return synth_edm_state_dict(1234)
+
+
+@pytest.fixture(scope="session")
+def gcn_sd():
+    from ml_conformer_generator_amd.weights import synth_adj_mat_seer_state_dict
+    return synth_adj_mat_seer_state_dict(4321)
+
+
+class TapeNoise:
+    """Replays a recorded flat noise tape as successive `shape`-sized draws."""
+
+    def __init__(self, flat, device="cpu"):
+        self.flat = torch.as_tensor(flat, dtype=torch.float32)
+        self.pos = 0
+        self.device = device
+
+    def __call__(self, shape):
+        n = int(np.prod(shape))
+        out = self.flat[self.pos:self.pos + n].reshape(shape)
+        self.pos += n
+        return out.to(self.device)

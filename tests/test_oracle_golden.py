@@ -1,0 +1,122 @@
+"""Pin the CPU oracle against outputs of the reference itself (tests/golden, made by
+tools/make_golden.py).  CPU-only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import TapeNoise, load_golden
+from oracle import diffusion_oracle as DO
+from oracle import egnn_oracle as EO
+from oracle import gcn_oracle as GO
+from oracle import host_oracle as HO
+
+torch.set_num_threads(8)
+
+
+def edge_mask_of(node_mask):
+    B, N, _ = node_mask.shape
+    nm = node_mask.squeeze(2)
+    em = nm.unsqueeze(1) * nm.unsqueeze(2) * (1 - torch.eye(N)).unsqueeze(0)
+    return em.reshape(B * N * N, 1)
+
+
+def test_gamma_tables_bit_exact():
+    g = load_golden("schedule.npz")
+    for T in (20, 100, 250, 1000):
+        assert torch.equal(DO.gamma_schedule(T, 1e-5), g[f"gamma_T{T}"])
+    # survey KATs
+    t20 = DO.gamma_schedule(20, 1e-5)
+    assert abs(float(t20[0]) - (-11.5115576)) < 1e-5 and abs(float(t20[20]) - 10.8447676) < 1e-5
+
+
+def test_input_construction():
+    g = load_golden("edm_input.npz")
+    torch.manual_seed(int(g["seed"]))
+    norms = {"mean": torch.tensor([105.0766, 473.1938, 537.4675]), "mad": torch.tensor([52.0409, 219.7475, 232.9718])}
+    nm, em, ctx = HO.edm_input(6, g["ref_context"], norms, 15, 19)
+    assert torch.equal(nm, g["node_mask"]) and torch.equal(em, g["edge_mask"]) and torch.equal(ctx, g["context"])
+    r, c = EO.dense_edge_index(3, 2)
+    assert torch.equal(torch.stack([r, c]), g["edges_n3_b2"])
+
+
+def test_context_kats():
+    g = load_golden("context_shape.npz")
+    for name in ("ceyyag", "yibfeu", "paba", "frag_yibfeu"):
+        xyz = g[f"{name}_xyz"]
+        c, rot = HO.context_shape(xyz - xyz.mean(0))
+        assert torch.allclose(c, g[f"{name}_context"], rtol=1e-6, atol=1e-4)
+    assert torch.allclose(g["ceyyag_context"], torch.tensor([50.589699, 105.313202, 133.522293]), atol=2e-3)
+
+
+@pytest.mark.parametrize("tag", ["b2n20", "b4n19", "b3n39", "b3n27_x30"])
+def test_dynamics_seam(edm_sd, tag):
+    g = load_golden(f"dynamics_{tag}.npz")
+    out = EO.egnn_dynamics(edm_sd, g["t"], g["xh"], g["node_mask"], edge_mask_of(g["node_mask"]), g["context"])
+    assert torch.allclose(out, g["out"], rtol=1e-5, atol=1e-6), float((out - g["out"]).abs().max())
+
+
+def test_single_block(edm_sd):
+    g = load_golden("block3_b2n20.npz")
+    nm = g["node_mask"]
+    B, N, _ = nm.shape
+    nmf, emf = nm.reshape(B * N, 1), edge_mask_of(nm)
+    row, col = EO.dense_edge_index(N, B)
+    d0, _ = EO.pair_geometry(g["x0"], row, col)
+    d1, _ = EO.pair_geometry(g["x_in"], row, col)
+    p = "dynamics.egnn.e_block_3."
+    h1, m1, _, _ = EO.gcl(edm_sd, p + "gcl_0.", g["h_in"], row, col, torch.cat([d1, d0], 1), nmf, emf)
+    assert torch.allclose(h1, g["h_after_gcl0"], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(m1[:N], g["m_gcl0_node0"], rtol=1e-5, atol=1e-6)
+    h, x = EO.equivariant_block(edm_sd, p, g["h_in"], g["x_in"], row, col, nmf, emf, d0)
+    assert torch.allclose(h, g["h_out"], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(x, g["x_out"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["sampler_T20_b4n19.npz", "sampler_T8_rs1.npz"])
+def test_sampler_trajectory(edm_sd, name):
+    g = load_golden(name)
+    nm = g["node_mask"]
+    s = DO.SamplerOracle(edm_sd, int(g["T"]), noise_fn=TapeNoise(g["noise"]))
+    s.trace = []
+    x, h = s.forward(nm, edge_mask_of(nm), g["context"], int(g["resample_steps"]))
+    assert s.noise_fn.pos == g["noise"].numel()          # same number of draws, same order
+    zt = torch.stack(s.trace)
+    assert torch.allclose(zt, g["z_trace"], rtol=1e-4, atol=1e-5), float((zt - g["z_trace"]).abs().max())
+    assert torch.allclose(x, g["x"], rtol=1e-4, atol=1e-5)
+    assert torch.equal(h.to(torch.int64), g["h"].to(torch.int64))
+
+
+def test_inpaint(edm_sd):
+    g = load_golden("inpaint_T5.npz")
+    nm = g["node_mask"]
+    s = DO.SamplerOracle(edm_sd, int(g["T"]), noise_fn=TapeNoise(g["noise"]))
+    s.trace = []
+    x, h = s.inpaint(nm, edge_mask_of(nm), g["context"], g["z_known"], g["fixed_mask"], 1, 3)
+    assert s.noise_fn.pos == g["noise"].numel()
+    assert torch.allclose(torch.stack(s.trace), g["z_trace"], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(x, g["x"], rtol=1e-4, atol=1e-5)
+    assert torch.equal(h.to(torch.int64), g["h"].to(torch.int64))
+
+
+def test_merge_fragments(edm_sd):
+    g = load_golden("merge_T10_L4.npz")
+    nm = g["node_mask"]
+    s = DO.SamplerOracle(edm_sd, int(g["T"]), noise_fn=TapeNoise(g["noise"]))
+    s.trace = []
+    x, h = s.merge_fragments(nm, edge_mask_of(nm), g["fixed_mask"], g["context"], g["z_known"], 4, 1, 3)
+    assert s.noise_fn.pos == g["noise"].numel()
+    assert torch.allclose(torch.stack(s.trace), g["z_trace"], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(x, g["x"], rtol=1e-4, atol=1e-5)
+    assert torch.equal(h.to(torch.int64), g["h"].to(torch.int64))
+    # diffusion_level > T fails exactly like the reference (quirk H5)
+    assert str(load_golden("merge_level_gt_T.npz")["error"]) == "IndexError"
+    with pytest.raises(IndexError):
+        s.merge_fragments(nm, edge_mask_of(nm), g["fixed_mask"], g["context"], g["z_known"], 50)
+
+
+def test_adj_mat_seer(gcn_sd):
+    g = load_golden("adj_mat_seer_b4.npz")
+    logits = GO.adj_mat_seer(gcn_sd, g["elements"], g["dist_mat"], g["adj_mat"])
+    assert torch.allclose(logits, g["logits"], rtol=1e-5, atol=1e-5), float((logits - g["logits"]).abs().max())
+    assert torch.equal(torch.argmax(logits, -1), g["argmax"])
+    assert torch.equal(logits, logits.transpose(1, 2))

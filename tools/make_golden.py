@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE in the build container.
+
+Runs only where /root/reference exists (never on the GPU box).  The reference
+modules are imported unmodified through a package shell (RDKit is absent: its
+modules are stubbed so that the pure-tensor helpers import; nothing RDKit-bound
+is executed).  Weights are the deterministic synthetic tensors of
+`ml_conformer_generator_amd.weights` loaded into the reference modules through
+their own `load_state_dict` - the checkpoint key layout is therefore exercised.
+
+Only inputs, seeds and reference OUTPUTS are written - no reference source.
+Usage:  python tools/make_golden.py  [--out tests/golden]
+"""
+import argparse
+import importlib
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+REF_SRC = "/root/reference/src"
+
+from ml_conformer_generator_amd import weights as W            # noqa: E402
+from ml_conformer_generator_amd.config import CONTEXT_NORMS      # noqa: E402
+from ml_conformer_generator_amd.mol_utils import parse_molblock_heavy_atoms  # noqa: E402
+
+
+def import_reference():
+    sys.path.insert(0, REF_SRC)
+    for n in ["rdkit", "rdkit.Chem", "rdkit.Chem.rdDetermineBonds", "rdkit.Chem.rdmolops", "rdkit.Chem.AllChem",
+              "rdkit.Chem.MolStandardize", "rdkit.Chem.MolStandardize.rdMolStandardize",
+              "rdkit.Chem.rdFingerprintGenerator", "rdkit.DataStructs", "rdkit.DataStructs.cDataStructs",
+              "rdkit.Geometry"]:
+        sys.modules[n] = MagicMock()
+    pkg = types.ModuleType("mlconfgen")
+    pkg.__path__ = [REF_SRC + "/mlconfgen"]
+    sys.modules["mlconfgen"] = pkg
+    egnn = importlib.import_module("mlconfgen.egnn")
+    ed = importlib.import_module("mlconfgen.equivariant_diffusion")
+    ams = importlib.import_module("mlconfgen.adj_mat_seer")
+    mu = importlib.import_module("mlconfgen.utils.mol_utils")
+    return egnn, ed, ams, mu
+
+
+class NoiseTape:
+    """Record every torch.randn draw (in call order) made while active."""
+
+    def __init__(self):
+        self.draws = []
+
+    def __enter__(self):
+        self._orig = torch.randn
+
+        def rec(*a, **k):
+            out = self._orig(*a, **k)
+            self.draws.append(out.clone())
+            return out
+        torch.randn = rec
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn = self._orig
+
+    def flat(self):
+        return np.concatenate([d.reshape(-1).numpy() for d in self.draws]).astype(np.float32)
+
+
+def build_edm(egnn, ed, T, sd):
+    dyn = egnn.EGNNDynamics(in_node_nf=9, context_node_nf=3, hidden_nf=420)
+    gm = ed.EquivariantDiffusion(dynamics=dyn, in_node_nf=8, timesteps=1000, noise_precision=1e-5)
+    gm.load_state_dict(sd)                                   # strict: checks the key layout
+    gm.gamma = ed.PredefinedNoiseSchedule(timesteps=T, precision=1e-5)
+    gm.time_steps = torch.flip(torch.arange(0, T), dims=[0])
+    gm.T = T
+    return gm.eval()
+
+
+def record_steps(gm):
+    trace = []
+    orig = gm.sample_p_zs_given_zt
+
+    def wrapped(*a, **k):
+        z = orig(*a, **k)
+        trace.append(z.clone())
+        return z
+    gm.sample_p_zs_given_zt = wrapped
+    return trace
+
+
+def synth_gcn_inputs(B, sizes, seed):
+    """Inputs built to the prepare_adj_mat_seer_input recipe (mol_utils.py:159-191):
+    elements zero-padded atomic numbers; dist_mat = distances + I (zero padded);
+    adj_mat = {0,1} connectivity + I."""
+    g = torch.Generator().manual_seed(seed)
+    Zs = torch.tensor([6, 7, 8, 9, 15, 16, 17, 35])
+    el = torch.zeros(B, 42, dtype=torch.long)
+    dm = torch.zeros(B, 42, 42)
+    am = torch.zeros(B, 42, 42)
+    for b, n in enumerate(sizes):
+        steps = torch.randn(n, 3, generator=g)
+        steps = 1.45 * steps / steps.norm(dim=1, keepdim=True)
+        xyz = torch.cumsum(steps, 0).double()
+        d = torch.sqrt(((xyz.unsqueeze(1) - xyz.unsqueeze(0)) ** 2).sum(-1))
+        el[b, :n] = Zs[torch.randint(0, 3, (n,), generator=g)]
+        dm[b, :n, :n] = d.float()
+        dm[b] += torch.eye(42)
+        conn = ((d < 1.8) & (d > 0)).float()
+        am[b, :n, :n] = conn
+        am[b] += torch.eye(42)
+        am[b][am[b] > 0] = 1
+    return el, dm, am
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    torch.set_num_threads(8)
+    egnn, ed, ams, mu = import_reference()
+    norms = {k: torch.tensor(v) for k, v in CONTEXT_NORMS.items()}
+    dummy_ctx = torch.tensor([53.6424, 108.3042, 151.4399])
+
+    def save(name, **kw):
+        np.savez_compressed(os.path.join(args.out, name), **{k: (v.numpy() if torch.is_tensor(v) else np.asarray(v))
+                                                              for k, v in kw.items()})
+        print("wrote", name, {k: tuple(np.asarray(v.numpy() if torch.is_tensor(v) else v).shape) for k, v in kw.items()})
+
+    # 1. noise-schedule tables (a4)
+    save("schedule.npz", **{f"gamma_T{T}": ed.PredefinedNoiseSchedule(T, 1e-5).gamma.detach() for T in (20, 100, 250, 1000)})
+
+    # 2. input construction (a16) + dense edge list pattern (F6)
+    torch.manual_seed(7)
+    nm, em, ctx = mu.prepare_edm_input(6, dummy_ctx, norms, 15, 19, torch.device("cpu"))
+    edges = egnn.EGNNDynamics.get_adj_matrix(3, 2, torch.device("cpu"))
+    save("edm_input.npz", seed=7, n_samples=6, min_n=15, max_n=19, ref_context=dummy_ctx,
+         node_mask=nm, edge_mask=em, context=ctx, edges_n3_b2=edges)
+
+    # 3. context KATs (a16) from the demo molecules' heavy atoms
+    kat = {}
+    for name in ("ceyyag", "yibfeu", "paba", "frag_yibfeu"):
+        xyz, zs = parse_molblock_heavy_atoms(open(f"/root/reference/assets/demo_files/{name}.mol").read())
+        centred = xyz - torch.mean(xyz, dim=0)
+        c, rot = mu.get_context_shape(centred)
+        kat[f"{name}_xyz"] = xyz
+        kat[f"{name}_z"] = torch.tensor(zs)
+        kat[f"{name}_context"] = c
+        kat[f"{name}_rotated"] = rot
+    save("context_shape.npz", **kat)
+
+    # 4. EGNN dynamics operator seam (a7-a13), synthetic weights seed 1234
+    sd = W.synth_edm_state_dict(1234)
+    gm = build_edm(egnn, ed, 100, sd)
+    for tag, B, N, lo, seed, scale in (("b2n20", 2, 20, 16, 11, 1.0), ("b4n19", 4, 19, 15, 12, 1.0),
+                                       ("b3n39", 3, 39, 15, 13, 1.0), ("b3n27_x30", 3, 27, 27, 14, 30.0)):
+        torch.manual_seed(seed)
+        nm, em, ctx = mu.prepare_edm_input(B, dummy_ctx, norms, lo, N, torch.device("cpu"))
+        z = gm.sample_combined_position_feature_noise(B, N, nm) * scale
+        t = torch.full((B, 1), 51.0) / 100
+        with torch.no_grad():
+            out = gm.dynamics(t, z, nm, em, ctx)
+        save(f"dynamics_{tag}.npz", t=t, xh=z, node_mask=nm, context=ctx, out=out, weight_seed=1234)
+
+    # 4b. a single EquivariantBlock and its GCL internals (a9, a11-a13) - kernel-level pins
+    torch.manual_seed(21)
+    B, N = 2, 20
+    nm, em, ctx = mu.prepare_edm_input(B, dummy_ctx, norms, 16, N, torch.device("cpu"))
+    nmf, emf = nm.view(B * N, 1), em.view(B * N * N, 1)
+    h_in = torch.randn(B * N, 420) * nmf
+    x_in = torch.randn(B * N, 3) * nmf
+    x0 = torch.randn(B * N, 3) * nmf
+    edges = egnn.EGNNDynamics.get_adj_matrix(N, B, torch.device("cpu"))
+    blk = gm.dynamics.egnn.e_block_3
+    with torch.no_grad():
+        d0, _ = egnn.coord2diff(x0, edges)
+        d1, unit = egnn.coord2diff(x_in, edges)
+        ea = torch.cat([d1, d0], dim=1)
+        h1, m1 = blk.gcl_0(h_in, edges, ea, nmf, emf)
+        h_out, x_out = blk(h_in, x_in, edges, nmf, emf, d0)
+    # m1 only for real edges of sample 0's node 0 (small pin on the edge MLP itself)
+    save("block3_b2n20.npz", node_mask=nm, h_in=h_in, x_in=x_in, x0=x0, h_after_gcl0=h1,
+         m_gcl0_node0=m1[:N], h_out=h_out, x_out=x_out, weight_seed=1234)
+
+    # 5. full sampler trajectory, config C1 shape (a1-a6): T=20, B=4, N=19
+    gm = build_edm(egnn, ed, 20, sd)
+    torch.manual_seed(31)
+    nm, em, ctx = mu.prepare_edm_input(4, dummy_ctx, norms, 15, 19, torch.device("cpu"))
+    trace = record_steps(gm)
+    with NoiseTape() as tape, torch.no_grad():
+        x, h = gm(nm, em, ctx, 0)
+    save("sampler_T20_b4n19.npz", node_mask=nm, context=ctx, noise=tape.flat(), z_trace=torch.stack(trace),
+         x=x, h=h, T=20, resample_steps=0, weight_seed=1234)
+
+    # 5b. resampling variant (T=8, resample_steps=1)
+    gm = build_edm(egnn, ed, 8, sd)
+    torch.manual_seed(32)
+    nm, em, ctx = mu.prepare_edm_input(2, dummy_ctx, norms, 15, 17, torch.device("cpu"))
+    trace = record_steps(gm)
+    with NoiseTape() as tape, torch.no_grad():
+        x, h = gm(nm, em, ctx, 1)
+    save("sampler_T8_rs1.npz", node_mask=nm, context=ctx, noise=tape.flat(), z_trace=torch.stack(trace),
+         x=x, h=h, T=8, resample_steps=1, weight_seed=1234)
+
+    # 6. inpaint + merge_fragments (a14) with a synthetic 8-atom fragment (frag_yibfeu heavy atoms)
+    fxyz, fz = parse_molblock_heavy_atoms(open("/root/reference/assets/demo_files/frag_yibfeu.mol").read())
+    fxyz = fxyz - fxyz.mean(0)
+    cls = {6: 0, 7: 1, 8: 2, 9: 3, 15: 4, 16: 5, 17: 6, 35: 7}
+    foh = torch.zeros(len(fz), 8, dtype=torch.long)
+    for i, zz in enumerate(fz):
+        foh[i, cls[zz]] = 1
+    B, N = 3, 19
+    gm = build_edm(egnn, ed, 5, sd)
+    torch.manual_seed(41)
+    nm, em, ctx = mu.prepare_edm_input(B, dummy_ctx, norms, 15, N, torch.device("cpu"))
+    n_f = fxyz.size(0)
+    z_known = torch.zeros(B, N, 11)
+    z_known[:, :n_f, :3] = fxyz
+    z_known[:, :n_f, 3:] = foh.float()
+    fixed = torch.zeros(B, N, 1)
+    fixed[:, :n_f] = 1.0
+    trace = record_steps(gm)
+    with NoiseTape() as tape, torch.no_grad():
+        x, h = gm.inpaint(nm, em, ctx, z_known, fixed, 1, 3)
+    save("inpaint_T5.npz", node_mask=nm, context=ctx, z_known=z_known, fixed_mask=fixed, noise=tape.flat(),
+         z_trace=torch.stack(trace), x=x, h=h, T=5, resample_steps=1, blend_power=3, weight_seed=1234)
+
+    gm = build_edm(egnn, ed, 10, sd)
+    torch.manual_seed(42)
+    # merge: z_known covers the full molecule (fixed fragment + "generated" remainder)
+    zk = torch.randn(B, N, 11) * nm
+    zk[:, :n_f, :3] = fxyz
+    zk[:, :n_f, 3:] = foh.float()
+    trace = record_steps(gm)
+    with NoiseTape() as tape, torch.no_grad():
+        x, h = gm.merge_fragments(nm, em, fixed, ctx, zk, diffusion_level=4, resample_steps=1, blend_power=3)
+    save("merge_T10_L4.npz", node_mask=nm, context=ctx, z_known=zk, fixed_mask=fixed, noise=tape.flat(),
+         z_trace=torch.stack(trace), x=x, h=h, T=10, diffusion_level=4, resample_steps=1, blend_power=3,
+         weight_seed=1234)
+    # the level > T failure mode (quirk H5)
+    try:
+        gm.merge_fragments(nm, em, fixed, ctx, zk, diffusion_level=50)
+        err = "none"
+    except Exception as e:  # noqa: BLE001
+        err = type(e).__name__
+    save("merge_level_gt_T.npz", error=np.array(err))
+
+    # 7. AdjMatSeer (a15), synthetic weights seed 4321
+    gsd = W.synth_adj_mat_seer_state_dict(4321)
+    gcn = ams.AdjMatSeer(dimension=42, n_hidden=2048, embedding_dim=64, num_embeddings=36, num_bond_types=5).eval()
+    gcn.load_state_dict(gsd)
+    el, dm, am = synth_gcn_inputs(4, [15, 17, 27, 39], seed=51)
+    with torch.no_grad():
+        logits = gcn(el, dm, am)
+    top2 = torch.topk(logits, 2, dim=-1).values
+    margin = (top2[..., 0] - top2[..., 1])
+    save("adj_mat_seer_b4.npz", elements=el, dist_mat=dm, adj_mat=am, logits=logits,
+         argmax=torch.argmax(logits, -1), margin=margin, weight_seed=4321)
+    print("min top-2 margin over all entries:", float(margin.min()))
+
+
+if __name__ == "__main__":
+    main()
