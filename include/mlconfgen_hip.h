@@ -1,0 +1,99 @@
+/* libmlconfgen_hip.so - C ABI of the MI355X (gfx950) denoising hot path of mlconfgen.
+ *
+ * The reference (Membrizard/ml_conformer_generator @ 2025-07-04) is pure Python/PyTorch and has no
+ * FFI; its operator boundary is the pair of module-call seams that its own ONNX export treats as
+ * operators.  Each entry point below names the reference interface it
+ * replaces.  Plain pointers and sizes only; every float buffer is fp32, row-major, contiguous and
+ * lives in DEVICE memory unless the name ends in `_host`.  `stream` is a hipStream_t (0 = default).
+ * All functions return 0 on success (MCG_OK) or a non-zero code; mcg_last_error() gives the text.
+ * No global mutable state except the opaque handles.
+ */
+#ifndef MLCONFGEN_HIP_H
+#define MLCONFGEN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mcg_egnn mcg_egnn;   /* packed EGNN weights (one per checkpoint)            */
+typedef struct mcg_plan mcg_plan;   /* batch geometry + workspace (one per batch of sizes)  */
+typedef struct mcg_gcn mcg_gcn;     /* packed AdjMatSeer weights + workspace                */
+
+const char* mcg_last_error(void);
+int mcg_abi_version(void);
+
+/* ---- EGNN weights.  Replaces `EquivariantDiffusion.load_state_dict(...)` of the dynamics
+ * (conformer_generator.py:90-95).  `tensors_host` are HOST pointers to the reference-layout
+ * fp32 tensors ([out,in] row-major, as nn.Linear stores them) in this order:
+ *   embedding.weight, embedding.bias, embedding_out.weight, embedding_out.bias, then for each
+ *   block k: gcl_0{edge_mlp.0.w, .0.b, edge_mlp.2.w, .2.b, node_mlp.0.w, .0.b, node_mlp.2.w, .2.b,
+ *   att_mlp.0.w, att_mlp.0.b}, gcl_1{same 10}, gcl_equiv{coord_mlp.0.w, .0.b, .2.w, .2.b, .4.w}
+ * (n_tensors = 4 + 25*n_blocks; hidden must be 420).  The library repacks them into MFMA
+ * fragment order and uploads them. */
+int mcg_egnn_create(const float* const* tensors_host, int n_tensors, int hidden, int n_blocks, mcg_egnn** out);
+void mcg_egnn_destroy(mcg_egnn* m);
+
+/* ---- Batch plan.  Replaces the per-call `get_adj_matrix` edge-list rebuild (egnn.py:475,515-541)
+ * and the node/edge masks (mol_utils.py:226-252): node_mask[b] is the prefix of n_nodes_host[b]
+ * ones, edge_mask = outer product minus diagonal.  edge_mt: 0 = auto, 1..3 = rows/16 per wave. */
+int mcg_plan_create(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_plan** out);
+void mcg_plan_destroy(mcg_plan* p);
+/* info[8] = {real nodes, real edges, edge_mt, edge waves, partial slots, B, N, 16-row edge tiles} */
+int mcg_plan_info(const mcg_plan* p, int32_t* info_host);
+
+/* ---- Op seam 1: out[B,N,11] = EGNNDynamics.forward(t[B,1], xh[B,N,11], node_mask, edge_mask,
+ * context[B,N,3])  (egnn.py:472-513; called from equivariant_diffusion.py:187).  Masks are those of
+ * the plan.  Inputs are not modified; `out` may not alias `xh`. */
+int mcg_egnn_dynamics(const mcg_egnn* m, mcg_plan* p, const float* t, const float* xh, const float* context,
+                      float* out, void* stream);
+
+/* Kernel-level pin: ONE EquivariantBlock (egnn.py:188-222) on compact node arrays
+ * h_io[M,420], x_io[M,3], x0[M,3] (M = real nodes of the plan, molecule-major). */
+int mcg_egnn_block_debug(const mcg_egnn* m, mcg_plan* p, int block, float* h_io, float* x_io, const float* x0,
+                         void* stream);
+
+/* ---- Sampler arithmetic (equivariant_diffusion.py).  randn_x[B,N,3] / randn_h[B,N,8] are RAW
+ * standard-normal draws (the caller draws them in the reference's order: x first, then h);
+ * masking and centre-of-gravity removal (:56-76) happen inside. */
+/* eps[B,N,11] = sample_combined_position_feature_noise (:341-363) */
+int mcg_sampler_noise(const mcg_plan* p, const float* randn_x, const float* randn_h, float* eps, void* stream);
+/* z <- sample_p_zs_given_zt (:295-339): one network call + ancestral update + mean removal.
+ * alpha_ts, c_eps = sigma2_ts/alpha_ts/sigma_t, c_noise = sigma_ts*sigma_s/sigma_t are the fp32
+ * scalars of :308-326; t_dev[B] holds t. */
+int mcg_sampler_step(const mcg_egnn* m, mcg_plan* p, float* z, const float* context, const float* t_dev,
+                     const float* randn_x, const float* randn_h, float alpha_ts, float c_eps, float c_noise,
+                     float* eps_hat_scratch, void* stream);
+/* x[B,N,3], h[B,N,8] (one-hot, float) = sample_p_xh_given_z0 (:261-285) */
+int mcg_sampler_decode(const mcg_egnn* m, mcg_plan* p, const float* z0, const float* context, const float* t_zero_dev,
+                       const float* randn_x, float inv_alpha0, float sigma0, float sigma_x, float norm_x, float norm_h,
+                       float* eps_hat_scratch, float* x_out, float* h_out, void* stream);
+/* mode 0: z = alpha_s*z_known + sigma_s*eps            (merge_fragments :548-559)
+ * mode 1: re-noise z_known, align the fixed fragment's centre of mass (:79-105), blend (:489-493) */
+int mcg_sampler_blend(const mcg_plan* p, float* z, const float* z_known, const float* fixed_mask, const float* randn_x,
+                      const float* randn_h, float alpha_s, float sigma_s, float blend, int mode, void* stream);
+
+/* ---- Stand-alone aggregate (unsorted_segment_sum of gate*m, egnn.py:49-64,418-437) over the compact
+ * real-edge list: node v owns n_rows[v] consecutive rows of m[E_r, D] starting at first_row[v];
+ * out[v,:] = sum_j gate[row]*m[row,:] / 100.  HBM-roofline probe; production fuses this. */
+int mcg_egnn_aggregate(const float* m, const float* gate, const int32_t* first_row, const int32_t* n_rows, float* out,
+                       int n_nodes, int D, void* stream);
+
+/* ---- Op seam 2: AdjMatSeer (adj_mat_seer.py:104-165).  tensors_host order (22):
+ *   gcn1..4.linear.{weight,bias}, resize.{weight,bias}, nodes_embedding.weight,
+ *   nodes_coord_fc.{weight,bias}, gcn1_dm..gcn3_dm.linear.{weight,bias}, dm_resize.{weight,bias},
+ *   dm_nodes_embedding.weight */
+int mcg_gcn_create(const float* const* tensors_host, int n_tensors, mcg_gcn** out);
+void mcg_gcn_destroy(mcg_gcn* g);
+/* logits[B,42,42,5] = adj_mat_seer(elements[B,42] int64, dist_mat[B,42,42], adj_mat[B,42,42]);
+ * bond[B,42,42] int8 = argmax over the 5 bond classes (the consumer's reduction, mol_utils.py:210).
+ * Either output may be NULL. */
+int mcg_gcn_forward(mcg_gcn* g, const int64_t* elements, const float* dist_mat, const float* adj_mat, float* logits,
+                    int8_t* bond, int B, void* stream);
+int mcg_gcn_check(mcg_gcn* g);   /* non-zero if an element id outside [0,36) was seen */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLCONFGEN_HIP_H */

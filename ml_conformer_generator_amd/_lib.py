@@ -1,0 +1,94 @@
+"""ctypes binding of libmlconfgen_hip.so (the C ABI in include/mlconfgen_hip.h).
+
+The library is the product: if it is missing or does not export a declared
+symbol, importing this module's `lib()` raises - there is no CPU/PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Sequence
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmlconfgen_hip.so")
+
+_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+_pp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/mlconfgen_hip.h one to one
+SIGNATURES: Dict[str, tuple] = {
+    "mcg_last_error": (C.c_char_p, []),
+    "mcg_abi_version": (_i, []),
+    "mcg_egnn_create": (_i, [_pp, _i, _i, _i, _pp]),
+    "mcg_egnn_destroy": (None, [_vp]),
+    "mcg_plan_create": (_i, [_i, _i, _vp, _i, _pp]),
+    "mcg_plan_destroy": (None, [_vp]),
+    "mcg_plan_info": (_i, [_vp, _vp]),
+    "mcg_egnn_dynamics": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mcg_egnn_block_debug": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "mcg_sampler_noise": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "mcg_sampler_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp]),
+    "mcg_sampler_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "mcg_sampler_blend": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _i, _vp]),
+    "mcg_egnn_aggregate": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mcg_gcn_create": (_i, [_pp, _i, _pp]),
+    "mcg_gcn_destroy": (None, [_vp]),
+    "mcg_gcn_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mcg_gcn_check": (_i, [_vp]),
+}
+
+_lib = None
+
+
+class McgError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise if the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise McgError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C ml_conformer_generator_amd/csrc`. There is no CPU fallback for the hot path.")
+    import torch  # noqa: F401  - loads the process's HIP runtime first (same SONAME as ours)
+    handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise McgError(f"{LIB_PATH} does not export `{name}` (stale build?)") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = handle
+    return handle
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = lib().mcg_last_error()
+        raise McgError(f"{what} failed (code {code}): {msg.decode() if msg else ''}")
+
+
+def host_ptr_array(tensors: Sequence) -> "C.Array":
+    """void*[n] of HOST data pointers of contiguous fp32 CPU tensors."""
+    arr = (C.c_void_p * len(tensors))()
+    for k, t in enumerate(tensors):
+        assert t.device.type == "cpu" and t.is_contiguous() and str(t.dtype) == "torch.float32"
+        arr[k] = t.data_ptr()
+    return arr
+
+
+def dptr(t) -> int:
+    """Device (or host) data pointer of a contiguous tensor, as int for ctypes."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "kernel operands must be contiguous"
+    return t.data_ptr()
+
+
+def current_stream_ptr(device) -> int:
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

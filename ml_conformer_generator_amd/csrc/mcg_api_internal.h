@@ -1,0 +1,8 @@
+// Internal glue between the translation units of libmlconfgen_hip.so.
+#pragma once
+#include "../../include/mlconfgen_hip.h"
+
+// accessors of the opaque plan (defined in mcg_egnn.hip)
+int mcg_plan_B(const mcg_plan* p);
+int mcg_plan_N(const mcg_plan* p);
+const int* mcg_plan_n_nodes(const mcg_plan* p);   // device pointer

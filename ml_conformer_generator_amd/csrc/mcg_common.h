@@ -1,0 +1,68 @@
+// Shared device helpers + packed-operand conventions for the gfx950 kernels.
+// Written for CDNA4 only (wave64, v_mfma_f32_16x16x4_f32); no CUDA compat paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define MCG_OK 0
+#define MCG_ERR_ARG 1
+#define MCG_ERR_HIP 2
+#define MCG_ERR_STATE 3
+
+#define MCG_HIP(call)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            mcg_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return MCG_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+extern "C" void mcg_set_error(const char* fmt, ...);
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------
+// Packed GEMM operand ("B-pack").  A weight W[n_out][k_in] (nn.Linear layout) of a layer
+// y = x W^T is stored as MFMA 16x16x4 B-fragments, one 64-float line per (k-step, n-tile):
+//     Bp[(step * n_tiles + nt) * 64 + lane] = W[16*nt + (lane & 15)][kperm(step, lane >> 4)]
+// K is consumed in groups of 16: group q, sub-step s (0..3), lane-group g = lane>>4 uses
+//     k = 16*q + 4*g + s
+// so that a lane's A-operand values for the 4 sub-steps of a group are 4 CONTIGUOUS floats
+// (one 16-byte load of the activation row).  K % 16 == 4*r leftover: r... handled as tail
+// steps with k = 16*Q + 4*s' + g  (s' = 0..r-1), i.e. one scalar per lane.
+// Rows n >= n_out are zero.  The summation order over k differs from a plain dot product
+// only by this fixed permutation (documented fp32 re-association).
+// ---------------------------------------------------------------------------------------
+__host__ __device__ inline int mcg_ksteps(int K) { return K / 4; }            // K % 4 == 0
+__host__ __device__ inline int mcg_kperm(int step, int g, int K) {
+    const int full = (K / 16) * 4;                  // steps covered by full 16-groups
+    if (step < full) return 16 * (step >> 2) + 4 * g + (step & 3);
+    return 16 * (K / 16) + 4 * (step - full) + g;   // tail: 4 consecutive k per step
+}
+
+__device__ __forceinline__ float mcg_silu(float x) {
+    // x * sigmoid(x); v_exp_f32 / v_rcp_f32 (~1 ulp each)
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+__device__ __forceinline__ float mcg_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+__device__ __forceinline__ f32x4 mcg_mfma(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// sum over the 16 lanes that share (lane >> 4): xor-butterfly inside a 16-lane row
+__device__ __forceinline__ float mcg_row16_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+// sum over the 4 lane-groups (lanes l, l^16, l^32, l^48)
+__device__ __forceinline__ float mcg_group4_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}

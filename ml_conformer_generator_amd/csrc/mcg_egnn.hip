@@ -1,0 +1,732 @@
+// EGNN denoiser (EGNNDynamics.forward, reference egnn.py:472-513) for gfx950.
+//
+// Data layout in HBM (all fp32):
+//   * nodes are COMPACT: molecule b owns rows node_off[b] .. node_off[b]+n_b-1 (padded
+//     slots of the reference's [B,N] layout are never materialised - they contribute
+//     exactly zero there, egnn.py:51,83,127,148);
+//   * node features h[M_r][HP], HP = 432 = 27 MFMA column tiles (420 real + 12 zero);
+//   * edges are never materialised.  The real directed edges (i != j) of all molecules
+//     form one flat row list  row = row_off[b] + i*(n_b-1) + jj,  j = jj + (jj >= i);
+//     a wave owns 16*MT consecutive rows and the FULL 432-column output tile of the
+//     edge MLP's second layer in registers, so the gate dot product, the mask and the
+//     per-node sum over j happen in the epilogue without the message tensor m_ij[E,420]
+//     (reference: 78 MB per layer at config 2) ever touching memory.
+//   * first edge-MLP layer is factorised per node:
+//        W1 [h_i | h_j | d2 | d0] + b1 = (Wa h_i + b1) + Wb h_j + wd*d2 + wd0*d0
+//     Pab[M_r][2*HP] holds (Wa h + b1 | Wb h); the per-edge sum + SiLU is generated
+//     straight into the MFMA A-operand registers.
+#include "mcg_gemm.h"
+#include "mcg_api_internal.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr int H = 420;       // hidden_nf (conformer_generator.py:70)
+constexpr int HP = 432;      // padded to 27 column tiles of 16
+constexpr int NT = 27;
+constexpr int KSTEPS = H / 4;   // 105 MFMA k-steps
+constexpr int IN_NF = 12;    // 8 classes + time + 3 context
+constexpr float NORM = 100.0f;  // egnn.py:435
+
+// ------------------------------------------------------------------------------ prep + embedding
+// h = embedding([h(8) | t | ctx(3)])  (egnn.py:484-493, :315); x, x0 = masked coordinates.
+__global__ __launch_bounds__(128) void k_prep_embed(const float* __restrict__ xh, const float* __restrict__ t,
+                                                     const float* __restrict__ ctx, const int* __restrict__ node_mol,
+                                                     const int* __restrict__ node_off, int N,
+                                                     const float* __restrict__ emb_wT,  // [12][HP]
+                                                     const float* __restrict__ emb_b,   // [HP]
+                                                     float* __restrict__ h, float* __restrict__ x, float* __restrict__ x0) {
+    const int v = blockIdx.x;
+    const int b = node_mol[v];
+    const int i = v - node_off[b];
+    const float* src = xh + ((size_t)b * N + i) * 11;
+    float f[IN_NF];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = src[3 + k];
+    f[8] = t[b];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) f[9 + k] = ctx[((size_t)b * N + i) * 3 + k];
+    if (threadIdx.x < 4) {
+        const float xv = threadIdx.x < 3 ? src[threadIdx.x] : 0.f;
+        x[(size_t)v * 4 + threadIdx.x] = xv;
+        x0[(size_t)v * 4 + threadIdx.x] = xv;
+    }
+    for (int col = threadIdx.x; col < HP; col += 128) {
+        float acc = emb_b[col];
+#pragma unroll
+        for (int k = 0; k < IN_NF; ++k) acc = fmaf(f[k], emb_wT[k * HP + col], acc);
+        h[(size_t)v * HP + col] = acc;   // pad columns: weights/bias are zero there
+    }
+}
+
+// ------------------------------------------------------------------------------ edge kernels
+struct EdgeArgs {
+    const float* pab;       // [M_r][2*HP]
+    const float* x;         // [M_r][4] current coordinates
+    const float* x0;        // [M_r][4] coordinates at network input (d0)
+    const float* wd;        // [HP] layer-1 weights of d2 (current squared distance)
+    const float* wd0;       // [HP] layer-1 weights of d0 (initial squared distance)
+    const float* Bp;        // packed second-layer weights (KSTEPS x NT x 64)
+    const float* b2;        // [HP]
+    const float* wv;        // [HP] attention weights (GCL) or coordinate head w5 (equiv)
+    float bv;               // attention bias (GCL)
+    const int* n_nodes; const int* node_off; const int* row_off; int B;
+    const int* tile_mol;    // molecule of the first row of every 16-row tile
+    const int* wave_nf;     // first compact node touched by each wave
+    const int* wave_poff;   // prefix offsets of (wave, node) partial slots
+    int n_rows; int n_mtiles;
+    float* P;               // GCL: [n_pslots][HP] partial sums;  equiv: [n_pslots][4]
+};
+
+template <int MT, bool EQUIV>
+__global__ __launch_bounds__(64) void k_edge(EdgeArgs p) {
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, c = lane & 15;
+    const int wave = blockIdx.x;
+    const int nf = p.wave_nf[wave];
+
+    // ---- decode this lane's A-operand rows (row = tile*16 + c)
+    int ni[MT], nj[MT], seg[MT];
+    float d2[MT], d02[MT], ux[MT], uy[MT], uz[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int tile = wave * MT + mt;
+        const int r = tile * 16 + c;
+        int vi = 0, vj = 0, sg = -1;
+        if (tile < p.n_mtiles && r < p.n_rows) {
+            int b = p.tile_mol[tile];
+            while (r >= p.row_off[b + 1]) ++b;
+            const int n = p.n_nodes[b];
+            const int local = r - p.row_off[b];
+            const int i = local / (n - 1);
+            const int jj = local - i * (n - 1);
+            const int j = jj + (jj >= i ? 1 : 0);
+            vi = p.node_off[b] + i;
+            vj = p.node_off[b] + j;
+            sg = vi - nf;
+        }
+        ni[mt] = vi; nj[mt] = vj; seg[mt] = sg;
+        const f32x4 xi = *reinterpret_cast<const f32x4*>(p.x + (size_t)vi * 4);
+        const f32x4 xj = *reinterpret_cast<const f32x4*>(p.x + (size_t)vj * 4);
+        const f32x4 yi = *reinterpret_cast<const f32x4*>(p.x0 + (size_t)vi * 4);
+        const f32x4 yj = *reinterpret_cast<const f32x4*>(p.x0 + (size_t)vj * 4);
+        const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
+        const float ex = yi[0] - yj[0], ey = yi[1] - yj[1], ez = yi[2] - yj[2];
+        d2[mt] = dx * dx + dy * dy + dz * dz;            // coord2diff radial (egnn.py:410-411)
+        d02[mt] = ex * ex + ey * ey + ez * ez;
+        if (EQUIV) {
+            const float inv = 1.0f / sqrtf(d2[mt] + 1e-8f);  // egnn.py:412-413
+            ux[mt] = dx * inv; uy[mt] = dy * inv; uz[mt] = dz * inv;
+        }
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* pa[MT];
+    const float* pb[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        pa[mt] = p.pab + (size_t)ni[mt] * (2 * HP) + 4 * g;
+        pb[mt] = p.pab + (size_t)nj[mt] * (2 * HP) + HP + 4 * g;
+    }
+    const float* bp = p.Bp + lane;
+
+    // ---- main loop: 26 groups of 16 k  (k = 16q + 4g + s)
+#pragma unroll 1
+    for (int q = 0; q < H / 16; ++q) {
+        const f32x4 wdv = *reinterpret_cast<const f32x4*>(p.wd + 16 * q + 4 * g);
+        const f32x4 w0v = *reinterpret_cast<const f32x4*>(p.wd0 + 16 * q + 4 * g);
+        f32x4 a4[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 va = *reinterpret_cast<const f32x4*>(pa[mt] + 16 * q);
+            const f32x4 vb = *reinterpret_cast<const f32x4*>(pb[mt] + 16 * q);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float pre = fmaf(w0v[s], d02[mt], fmaf(wdv[s], d2[mt], va[s] + vb[s]));
+                a4[mt][s] = mcg_silu(pre);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float b = bp[nt * 64];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mcg_mfma(a4[mt][s], b, acc[mt][nt]);
+            }
+            bp += NT * 64;
+        }
+    }
+    {   // tail k-step: k = 416 + g
+        const int k = (H / 16) * 16 + g;
+        const float wdk = p.wd[k], w0k = p.wd0[k];
+        float a1[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float va = p.pab[(size_t)ni[mt] * (2 * HP) + k];
+            const float vb = p.pab[(size_t)nj[mt] * (2 * HP) + HP + k];
+            a1[mt] = mcg_silu(fmaf(w0k, d02[mt], fmaf(wdk, d2[mt], va + vb)));
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float b = bp[nt * 64];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mcg_mfma(a1[mt], b, acc[mt][nt]);
+        }
+    }
+
+    // ---- epilogue.  C/D layout: column = 16*nt + c, row = 4*g + r of tile mt.
+    float part[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[mt][r] = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float b2 = p.b2[nt * 16 + c];
+        const float wv = p.wv[nt * 16 + c];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float m = mcg_silu(acc[mt][nt][r] + b2);      // second Linear + SiLU (egnn.py:26-27)
+                acc[mt][nt][r] = m;
+                part[mt][r] = fmaf(wv, m, part[mt][r]);
+            }
+    }
+    int rseg[MT][4];
+    float scale[MT][4];
+    float tx[MT][4], ty[MT][4], tz[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dot = mcg_row16_sum(part[mt][r]);
+            const int src = 4 * g + r;                    // lane whose A-row is this C-row
+            rseg[mt][r] = __shfl(seg[mt], src, 64);
+            if (EQUIV) {
+                // trans = coord_diff * phi * edge_mask (egnn.py:124-127)
+                tx[mt][r] = __shfl(ux[mt], src, 64) * dot;
+                ty[mt][r] = __shfl(uy[mt], src, 64) * dot;
+                tz[mt][r] = __shfl(uz[mt], src, 64) * dot;
+            } else {
+                scale[mt][r] = mcg_sigmoid(dot + p.bv);   // att_mlp (egnn.py:36,48)
+            }
+        }
+
+    const int nseg = p.wave_poff[wave + 1] - p.wave_poff[wave];
+    const int pbase = p.wave_poff[wave];
+    if (EQUIV) {
+        for (int s = 0; s < nseg; ++s) {
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (rseg[mt][r] == s) { sx += tx[mt][r]; sy += ty[mt][r]; sz += tz[mt][r]; }
+            sx = mcg_group4_sum(sx); sy = mcg_group4_sum(sy); sz = mcg_group4_sum(sz);
+            if (lane == 0) {
+                float* dst = p.P + (size_t)(pbase + s) * 4;
+                dst[0] = sx; dst[1] = sy; dst[2] = sz; dst[3] = 0.f;
+            }
+        }
+    } else {
+        for (int s = 0; s < nseg; ++s) {
+            float w[MT][4];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[mt][r] = rseg[mt][r] == s ? scale[mt][r] : 0.f;
+            float* dst = p.P + (size_t)(pbase + s) * HP + c;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float v = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v = fmaf(acc[mt][nt][r], w[mt][r], v);   // m * att * edge_mask
+                v = mcg_group4_sum(v);
+                if (g == 0) dst[nt * 16] = v;
+            }
+        }
+    }
+}
+
+// agg[v] = (sum of the per-wave partials that cover node v) / 100   (egnn.py:429-435)
+__global__ __launch_bounds__(128) void k_combine_agg(const float* __restrict__ P, const int* __restrict__ node_mol,
+                                                      const int* __restrict__ node_off, const int* __restrict__ row_off,
+                                                      const int* __restrict__ n_nodes, const int* __restrict__ wave_nf,
+                                                      const int* __restrict__ wave_poff, int rows_per_wave,
+                                                      float* __restrict__ agg) {
+    const int v = blockIdx.x;
+    const int b = node_mol[v];
+    const int n = n_nodes[b];
+    const int i = v - node_off[b];
+    const int first = row_off[b] + i * (n - 1);
+    const int w_lo = first / rows_per_wave, w_hi = (first + n - 2) / rows_per_wave;
+    for (int col = threadIdx.x; col < HP; col += 128) {
+        float s = 0.f;
+        if (n > 1)
+            for (int w = w_lo; w <= w_hi; ++w) s += P[(size_t)(wave_poff[w] + v - wave_nf[w]) * HP + col];
+        agg[(size_t)v * HP + col] = s / NORM;
+    }
+}
+
+// x[v] = x[v] + (sum of partials) / 100   (egnn.py:128-134; node mask is implicit)
+__global__ void k_coord_update(const float* __restrict__ Px, const int* __restrict__ node_mol,
+                               const int* __restrict__ node_off, const int* __restrict__ row_off,
+                               const int* __restrict__ n_nodes, const int* __restrict__ wave_nf,
+                               const int* __restrict__ wave_poff, int rows_per_wave, int M, float* __restrict__ x) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = idx >> 2, comp = idx & 3;
+    if (v >= M || comp == 3) return;
+    const int b = node_mol[v];
+    const int n = n_nodes[b];
+    if (n <= 1) return;
+    const int i = v - node_off[b];
+    const int first = row_off[b] + i * (n - 1);
+    const int w_lo = first / rows_per_wave, w_hi = (first + n - 2) / rows_per_wave;
+    float s = 0.f;
+    for (int w = w_lo; w <= w_hi; ++w) s += Px[(size_t)(wave_poff[w] + v - wave_nf[w]) * 4 + comp];
+    x[(size_t)v * 4 + comp] += s / NORM;
+}
+
+// ------------------------------------------------------------------------------ output head
+// h_final = embedding_out(h) (first 8 of 12 channels kept), vel = (x - x0) with the masked
+// mean removed; padded slots of out[B,N,11] are zero  (egnn.py:398-399, :499-513).
+__global__ __launch_bounds__(64) void k_output(const float* __restrict__ h, const float* __restrict__ x,
+                                                const float* __restrict__ x0, const int* __restrict__ n_nodes,
+                                                const int* __restrict__ node_off, int N,
+                                                const float* __restrict__ out_w,  // [12][HP]
+                                                const float* __restrict__ out_b, float* __restrict__ out) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int n = n_nodes[b];
+    const int v0 = node_off[b];
+    // masked mean of the velocity
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int i = lane; i < n; i += 64) {
+        sx += x[(size_t)(v0 + i) * 4 + 0] - x0[(size_t)(v0 + i) * 4 + 0];
+        sy += x[(size_t)(v0 + i) * 4 + 1] - x0[(size_t)(v0 + i) * 4 + 1];
+        sz += x[(size_t)(v0 + i) * 4 + 2] - x0[(size_t)(v0 + i) * 4 + 2];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sx += __shfl_xor(sx, o, 64); sy += __shfl_xor(sy, o, 64); sz += __shfl_xor(sz, o, 64);
+    }
+    const float inv_n = n > 0 ? 1.0f / (float)n : 0.f;
+    const float mx = sx * inv_n, my = sy * inv_n, mz = sz * inv_n;
+    float* ob = out + (size_t)b * N * 11;
+    for (int i = 0; i < N; ++i) {
+        float* o = ob + (size_t)i * 11;
+        if (i >= n) {
+            if (lane < 11) o[lane] = 0.f;
+            continue;
+        }
+        const float* hr = h + (size_t)(v0 + i) * HP;
+        float accv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) accv[k] = 0.f;
+        for (int col = lane; col < H; col += 64) {
+            const float hv = hr[col];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) accv[k] = fmaf(hv, out_w[k * HP + col], accv[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float s = accv[k];
+            for (int of = 32; of > 0; of >>= 1) s += __shfl_xor(s, of, 64);
+            accv[k] = s + out_b[k];
+        }
+        if (lane == 0) {
+            o[0] = (x[(size_t)(v0 + i) * 4 + 0] - x0[(size_t)(v0 + i) * 4 + 0]) - mx;
+            o[1] = (x[(size_t)(v0 + i) * 4 + 1] - x0[(size_t)(v0 + i) * 4 + 1]) - my;
+            o[2] = (x[(size_t)(v0 + i) * 4 + 2] - x0[(size_t)(v0 + i) * 4 + 2]) - mz;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[3 + k] = accv[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ host: packing
+template <class F>
+void pack_B(std::vector<float>& dst, int K, int n_tiles, F value /* (n, k) -> W */) {
+    const int steps = K / 4;
+    dst.assign((size_t)steps * n_tiles * 64, 0.f);
+    for (int st = 0; st < steps; ++st)
+        for (int nt = 0; nt < n_tiles; ++nt)
+            for (int l = 0; l < 64; ++l) {
+                const int k = mcg_kperm(st, l >> 4, K);
+                const int n = nt * 16 + (l & 15);
+                dst[((size_t)st * n_tiles + nt) * 64 + l] = value(n, k);
+            }
+}
+
+int upload(const std::vector<float>& v, float** d) {
+    MCG_HIP(hipMalloc((void**)d, v.size() * sizeof(float)));
+    MCG_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return MCG_OK;
+}
+int upload_i(const std::vector<int>& v, int** d) {
+    MCG_HIP(hipMalloc((void**)d, (v.size() ? v.size() : 1) * sizeof(int)));
+    if (v.size()) MCG_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+    return MCG_OK;
+}
+
+struct EdgeLayer {      // second layer + head of an edge MLP, and its factorised first layer
+    float *pab_Bp = nullptr, *pab_bias = nullptr, *wd = nullptr, *wd0 = nullptr;
+    float *w2_Bp = nullptr, *b2 = nullptr, *wv = nullptr;
+    float bv = 0.f;
+};
+struct NodeLayer {
+    float *w3_Bp = nullptr, *b3 = nullptr, *w4_Bp = nullptr, *b4 = nullptr;
+};
+
+}  // namespace
+
+struct mcg_egnn {
+    int n_blocks = 0;
+    float *emb_wT = nullptr, *emb_b = nullptr, *out_w = nullptr, *out_b = nullptr;
+    std::vector<EdgeLayer> gcl_edge;   // 2 per block
+    std::vector<NodeLayer> gcl_node;   // 2 per block
+    std::vector<EdgeLayer> equiv;      // 1 per block
+    std::vector<void*> allocs;
+};
+
+struct mcg_plan {
+    int B = 0, N = 0, M = 0, n_rows = 0, n_mtiles = 0, MT = 1, n_waves = 0, n_pslots = 0;
+    int *n_nodes = nullptr, *node_off = nullptr, *row_off = nullptr, *tile_mol = nullptr, *wave_nf = nullptr,
+        *wave_poff = nullptr, *node_mol = nullptr;
+    float *x = nullptr, *x0 = nullptr, *h = nullptr, *h2 = nullptr, *pab = nullptr, *agg = nullptr, *t1 = nullptr,
+          *P = nullptr, *Px = nullptr;
+    std::vector<void*> allocs;
+};
+
+namespace {
+
+int build_edge_layer(mcg_egnn* m, EdgeLayer& L, const float* w1 /*[420][842]*/, const float* b1, const float* w2,
+                     const float* b2, const float* wv, float bv) {
+    std::vector<float> buf;
+    // (Wa | Wb): 54 column tiles over K = 420
+    pack_B(buf, H, 2 * NT, [&](int n, int k) -> float {
+        if (n < HP) return n < H ? w1[(size_t)n * (2 * H + 2) + k] : 0.f;
+        const int nn = n - HP;
+        return nn < H ? w1[(size_t)nn * (2 * H + 2) + H + k] : 0.f;
+    });
+    if (int e = upload(buf, &L.pab_Bp)) return e;
+    m->allocs.push_back(L.pab_Bp);
+    std::vector<float> v(2 * HP, 0.f);
+    for (int n = 0; n < H; ++n) v[n] = b1[n];
+    if (int e = upload(v, &L.pab_bias)) return e;
+    m->allocs.push_back(L.pab_bias);
+    v.assign(HP, 0.f);
+    for (int n = 0; n < H; ++n) v[n] = w1[(size_t)n * (2 * H + 2) + 2 * H];       // current d2 column (egnn.py:199)
+    if (int e = upload(v, &L.wd)) return e;
+    m->allocs.push_back(L.wd);
+    for (int n = 0; n < H; ++n) v[n] = w1[(size_t)n * (2 * H + 2) + 2 * H + 1];   // initial d2 column
+    if (int e = upload(v, &L.wd0)) return e;
+    m->allocs.push_back(L.wd0);
+    pack_B(buf, H, NT, [&](int n, int k) -> float { return n < H ? w2[(size_t)n * H + k] : 0.f; });
+    if (int e = upload(buf, &L.w2_Bp)) return e;
+    m->allocs.push_back(L.w2_Bp);
+    v.assign(HP, 0.f);
+    for (int n = 0; n < H; ++n) v[n] = b2[n];
+    if (int e = upload(v, &L.b2)) return e;
+    m->allocs.push_back(L.b2);
+    v.assign(HP, 0.f);
+    for (int n = 0; n < H; ++n) v[n] = wv[n];
+    if (int e = upload(v, &L.wv)) return e;
+    m->allocs.push_back(L.wv);
+    L.bv = bv;
+    return MCG_OK;
+}
+
+int build_node_layer(mcg_egnn* m, NodeLayer& L, const float* w3 /*[420][840]*/, const float* b3, const float* w4,
+                     const float* b4) {
+    std::vector<float> buf, seg2;
+    // two K segments: [h | agg]  (egnn.py:66)
+    pack_B(buf, H, NT, [&](int n, int k) -> float { return n < H ? w3[(size_t)n * (2 * H) + k] : 0.f; });
+    pack_B(seg2, H, NT, [&](int n, int k) -> float { return n < H ? w3[(size_t)n * (2 * H) + H + k] : 0.f; });
+    buf.insert(buf.end(), seg2.begin(), seg2.end());
+    if (int e = upload(buf, &L.w3_Bp)) return e;
+    m->allocs.push_back(L.w3_Bp);
+    std::vector<float> v(HP, 0.f);
+    for (int n = 0; n < H; ++n) v[n] = b3[n];
+    if (int e = upload(v, &L.b3)) return e;
+    m->allocs.push_back(L.b3);
+    pack_B(buf, H, NT, [&](int n, int k) -> float { return n < H ? w4[(size_t)n * H + k] : 0.f; });
+    if (int e = upload(buf, &L.w4_Bp)) return e;
+    m->allocs.push_back(L.w4_Bp);
+    for (int n = 0; n < H; ++n) v[n] = b4[n];
+    if (int e = upload(v, &L.b4)) return e;
+    m->allocs.push_back(L.b4);
+    return MCG_OK;
+}
+
+template <int MT>
+void launch_edge(bool equiv, const EdgeArgs& a, int n_waves, hipStream_t s) {
+    if (equiv) hipLaunchKernelGGL((k_edge<MT, true>), dim3(n_waves), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((k_edge<MT, false>), dim3(n_waves), dim3(64), 0, s, a);
+}
+
+int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipStream_t s) {
+    if (pl->n_waves == 0) return MCG_OK;
+    EdgeArgs a;
+    a.pab = pl->pab; a.x = pl->x; a.x0 = pl->x0; a.wd = L.wd; a.wd0 = L.wd0; a.Bp = L.w2_Bp; a.b2 = L.b2;
+    a.wv = L.wv; a.bv = L.bv; a.n_nodes = pl->n_nodes; a.node_off = pl->node_off; a.row_off = pl->row_off;
+    a.B = pl->B; a.tile_mol = pl->tile_mol; a.wave_nf = pl->wave_nf; a.wave_poff = pl->wave_poff;
+    a.n_rows = pl->n_rows; a.n_mtiles = pl->n_mtiles; a.P = P;
+    switch (pl->MT) {
+        case 1: launch_edge<1>(equiv, a, pl->n_waves, s); break;
+        case 2: launch_edge<2>(equiv, a, pl->n_waves, s); break;
+        default: launch_edge<3>(equiv, a, pl->n_waves, s); break;
+    }
+    MCG_HIP(hipGetLastError());
+    return MCG_OK;
+}
+
+int gemm(const float* A1, int lda1, int K1, const float* A2, int lda2, int K2, const float* Bp, const float* bias,
+         const float* resid, int ldr, float* C, int ldc, int M, int n_tiles, int n_store, int act, hipStream_t s) {
+    McgGemmArgs g;
+    g.A1 = A1; g.lda1 = lda1; g.K1 = K1; g.A2 = A2; g.lda2 = lda2; g.K2 = K2; g.Bp = Bp; g.bias = bias;
+    g.resid = resid; g.ldr = ldr; g.C = C; g.ldc = ldc; g.M = M; g.n_tiles = n_tiles; g.n_store = n_store; g.act = act;
+    MCG_HIP(mcg_gemm_launch(g, s));
+    return MCG_OK;
+}
+
+// One GCL layer on the plan's compact state: h (in pl->h) -> pl->h  (egnn.py:70-85)
+int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s) {
+    const EdgeLayer& E = m->gcl_edge[layer];
+    const NodeLayer& Nl = m->gcl_node[layer];
+    const int M = pl->M;
+    if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
+                     MCG_ACT_NONE, s)) return e;
+    if (int e = run_edge(pl, E, false, pl->P, s)) return e;
+    hipLaunchKernelGGL(k_combine_agg, dim3(M), dim3(128), 0, s, pl->P, pl->node_mol, pl->node_off, pl->row_off,
+                       pl->n_nodes, pl->wave_nf, pl->wave_poff, 16 * pl->MT, pl->agg);
+    MCG_HIP(hipGetLastError());
+    // node_mlp: h + W4 silu(W3 [h | agg] + b3) + b4   (egnn.py:30-34,66-67)
+    if (int e = gemm(pl->h, HP, H, pl->agg, HP, H, Nl.w3_Bp, Nl.b3, nullptr, 0, pl->t1, HP, M, NT, HP, MCG_ACT_SILU, s))
+        return e;
+    if (int e = gemm(pl->t1, HP, H, nullptr, 0, 0, Nl.w4_Bp, Nl.b4, pl->h, HP, pl->h2, HP, M, NT, HP, MCG_ACT_NONE, s))
+        return e;
+    std::swap(pl->h, pl->h2);
+    return MCG_OK;
+}
+
+int run_equiv(const mcg_egnn* m, mcg_plan* pl, int block, hipStream_t s) {
+    const EdgeLayer& E = m->equiv[block];
+    const int M = pl->M;
+    if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
+                     MCG_ACT_NONE, s)) return e;
+    if (int e = run_edge(pl, E, true, pl->Px, s)) return e;
+    const int threads = M * 4;
+    hipLaunchKernelGGL(k_coord_update, dim3((threads + 255) / 256), dim3(256), 0, s, pl->Px, pl->node_mol, pl->node_off,
+                       pl->row_off, pl->n_nodes, pl->wave_nf, pl->wave_poff, 16 * pl->MT, M, pl->x);
+    MCG_HIP(hipGetLastError());
+    return MCG_OK;
+}
+
+int run_block(const mcg_egnn* m, mcg_plan* pl, int block, hipStream_t s) {
+    // d2 / x_hat are those of the block's INPUT coordinates for all three sub-layers (egnn.py:197-219):
+    // x is only written by the coordinate update at the end of the block.
+    if (int e = run_gcl(m, pl, 2 * block, s)) return e;
+    if (int e = run_gcl(m, pl, 2 * block + 1, s)) return e;
+    return run_equiv(m, pl, block, s);
+}
+
+}  // namespace
+
+int mcg_plan_B(const mcg_plan* p) { return p->B; }
+int mcg_plan_N(const mcg_plan* p) { return p->N; }
+const int* mcg_plan_n_nodes(const mcg_plan* p) { return p->n_nodes; }
+
+// =========================================================================== C ABI
+extern "C" {
+
+int mcg_egnn_create(const float* const* tensors, int n_tensors, int hidden, int n_blocks, mcg_egnn** out) {
+    if (!tensors || !out || hidden != H || n_blocks < 1 || n_tensors != 4 + n_blocks * 25) {
+        mcg_set_error("mcg_egnn_create: bad arguments (hidden must be %d, n_tensors = 4 + 25*n_blocks)", H);
+        return MCG_ERR_ARG;
+    }
+    mcg_egnn* m = new mcg_egnn();
+    m->n_blocks = n_blocks;
+    const float* const* t = tensors;
+    // embedding (420x12) / bias, embedding_out (12x420) / bias
+    std::vector<float> v((size_t)IN_NF * HP, 0.f);
+    for (int n = 0; n < H; ++n)
+        for (int k = 0; k < IN_NF; ++k) v[(size_t)k * HP + n] = t[0][(size_t)n * IN_NF + k];
+    if (int e = upload(v, &m->emb_wT)) return e;
+    v.assign(HP, 0.f);
+    for (int n = 0; n < H; ++n) v[n] = t[1][n];
+    if (int e = upload(v, &m->emb_b)) return e;
+    v.assign((size_t)IN_NF * HP, 0.f);
+    for (int o = 0; o < IN_NF; ++o)
+        for (int k = 0; k < H; ++k) v[(size_t)o * HP + k] = t[2][(size_t)o * H + k];
+    if (int e = upload(v, &m->out_w)) return e;
+    v.assign(16, 0.f);
+    for (int o = 0; o < IN_NF; ++o) v[o] = t[3][o];
+    if (int e = upload(v, &m->out_b)) return e;
+    m->allocs.insert(m->allocs.end(), {(void*)m->emb_wT, (void*)m->emb_b, (void*)m->out_w, (void*)m->out_b});
+    m->gcl_edge.resize(2 * n_blocks);
+    m->gcl_node.resize(2 * n_blocks);
+    m->equiv.resize(n_blocks);
+    int idx = 4;
+    for (int b = 0; b < n_blocks; ++b) {
+        for (int gi = 0; gi < 2; ++gi) {
+            const float* const* q = t + idx;   // edge0.w,b edge2.w,b node0.w,b node2.w,b att.w,b
+            if (int e = build_edge_layer(m, m->gcl_edge[2 * b + gi], q[0], q[1], q[2], q[3], q[8], q[9][0])) return e;
+            if (int e = build_node_layer(m, m->gcl_node[2 * b + gi], q[4], q[5], q[6], q[7])) return e;
+            idx += 10;
+        }
+        const float* const* q = t + idx;       // coord0.w,b coord2.w,b coord4.w
+        if (int e = build_edge_layer(m, m->equiv[b], q[0], q[1], q[2], q[3], q[4], 0.f)) return e;
+        idx += 5;
+    }
+    *out = m;
+    return MCG_OK;
+}
+
+void mcg_egnn_destroy(mcg_egnn* m) {
+    if (!m) return;
+    for (void* p : m->allocs) (void)hipFree(p);
+    delete m;
+}
+
+int mcg_plan_create(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_plan** out) {
+    if (B < 1 || N < 1 || !n_nodes_host || !out) {
+        mcg_set_error("mcg_plan_create: bad arguments");
+        return MCG_ERR_ARG;
+    }
+    mcg_plan* p = new mcg_plan();
+    p->B = B; p->N = N;
+    std::vector<int> nn(B), node_off(B + 1, 0), row_off(B + 1, 0);
+    for (int b = 0; b < B; ++b) {
+        if (n_nodes_host[b] < 0 || n_nodes_host[b] > N) {
+            mcg_set_error("mcg_plan_create: n_nodes[%d]=%d outside [0,%d]", b, n_nodes_host[b], N);
+            delete p;
+            return MCG_ERR_ARG;
+        }
+        nn[b] = n_nodes_host[b];
+        node_off[b + 1] = node_off[b] + nn[b];
+        row_off[b + 1] = row_off[b] + nn[b] * (nn[b] > 0 ? nn[b] - 1 : 0);
+    }
+    p->M = node_off[B];
+    p->n_rows = row_off[B];
+    p->n_mtiles = (p->n_rows + 15) / 16;
+    // rows per wave: minimise (rounds over the 1024 SIMDs) x (tiles per wave); ties -> larger tile
+    int best = 1;
+    long best_cost = -1;
+    // (MT = 3 needs 324 accumulator registers: hipcc spills it - kept for experiments only)
+    for (int mt = 1; mt <= 2; ++mt) {
+        const long waves = (p->n_mtiles + mt - 1) / mt;
+        const long cost = ((waves + 1023) / 1024) * mt;
+        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = mt; }
+    }
+    if (edge_mt >= 1 && edge_mt <= 3) best = edge_mt;
+    if (const char* e = getenv("MCG_EDGE_MT")) { const int v = atoi(e); if (v >= 1 && v <= 3) best = v; }
+    p->MT = best;
+    p->n_waves = (p->n_mtiles + best - 1) / best;
+    const int R = 16 * best;
+
+    std::vector<int> node_mol(p->M), tile_mol(p->n_mtiles + 1, 0), wave_nf(p->n_waves + 1, 0), wave_poff(p->n_waves + 1, 0);
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < nn[b]; ++i) node_mol[node_off[b] + i] = b;
+    auto node_of_row = [&](int r, int& bcur) {
+        while (r >= row_off[bcur + 1]) ++bcur;
+        return node_off[bcur] + (r - row_off[bcur]) / (nn[bcur] - 1);
+    };
+    {
+        int bcur = 0;
+        for (int t = 0; t < p->n_mtiles; ++t) {
+            (void)node_of_row(t * 16, bcur);
+            tile_mol[t] = bcur;
+        }
+        int b1 = 0, b2 = 0;
+        for (int w = 0; w < p->n_waves; ++w) {
+            const int r_first = w * R;
+            const int r_last = std::min(p->n_rows, (w + 1) * R) - 1;
+            const int nfirst = node_of_row(r_first, b1);
+            const int nlast = node_of_row(r_last, b2);
+            wave_nf[w] = nfirst;
+            wave_poff[w + 1] = wave_poff[w] + (nlast - nfirst + 1);
+        }
+        p->n_pslots = wave_poff[p->n_waves];
+    }
+    int e = 0;
+    e |= upload_i(nn, &p->n_nodes); e |= upload_i(node_off, &p->node_off); e |= upload_i(row_off, &p->row_off);
+    e |= upload_i(tile_mol, &p->tile_mol); e |= upload_i(wave_nf, &p->wave_nf); e |= upload_i(wave_poff, &p->wave_poff);
+    e |= upload_i(node_mol, &p->node_mol);
+    if (e) { delete p; return MCG_ERR_HIP; }
+    p->allocs.insert(p->allocs.end(), {(void*)p->n_nodes, (void*)p->node_off, (void*)p->row_off, (void*)p->tile_mol,
+                                       (void*)p->wave_nf, (void*)p->wave_poff, (void*)p->node_mol});
+    const size_t M1 = (size_t)(p->M > 0 ? p->M : 1);
+    struct { float** ptr; size_t n; } bufs[] = {
+        {&p->x, M1 * 4}, {&p->x0, M1 * 4}, {&p->h, M1 * HP}, {&p->h2, M1 * HP}, {&p->pab, M1 * 2 * HP},
+        {&p->agg, M1 * HP}, {&p->t1, M1 * HP}, {&p->P, (size_t)(p->n_pslots + 1) * HP}, {&p->Px, (size_t)(p->n_pslots + 1) * 4}};
+    for (auto& b : bufs) {
+        MCG_HIP(hipMalloc((void**)b.ptr, b.n * sizeof(float)));
+        MCG_HIP(hipMemset(*b.ptr, 0, b.n * sizeof(float)));
+        p->allocs.push_back(*b.ptr);
+    }
+    *out = p;
+    return MCG_OK;
+}
+
+void mcg_plan_destroy(mcg_plan* p) {
+    if (!p) return;
+    for (void* q : p->allocs) (void)hipFree(q);
+    delete p;
+}
+
+int mcg_plan_info(const mcg_plan* p, int32_t* info /*[8]*/) {
+    if (!p || !info) return MCG_ERR_ARG;
+    info[0] = p->M; info[1] = p->n_rows; info[2] = p->MT; info[3] = p->n_waves; info[4] = p->n_pslots;
+    info[5] = p->B; info[6] = p->N; info[7] = p->n_mtiles;
+    return MCG_OK;
+}
+
+// out[B,N,11] = EGNNDynamics.forward(t[B], xh[B,N,11], node_mask==prefix(n_nodes), context[B,N,3])
+int mcg_egnn_dynamics(const mcg_egnn* m, mcg_plan* pl, const float* t, const float* xh, const float* context,
+                      float* out, void* stream) {
+    if (!m || !pl || !t || !xh || !context || !out) { mcg_set_error("mcg_egnn_dynamics: null argument"); return MCG_ERR_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    if (pl->M > 0) {
+        hipLaunchKernelGGL(k_prep_embed, dim3(pl->M), dim3(128), 0, s, xh, t, context, pl->node_mol, pl->node_off, pl->N,
+                           m->emb_wT, m->emb_b, pl->h, pl->x, pl->x0);
+        MCG_HIP(hipGetLastError());
+        for (int b = 0; b < m->n_blocks; ++b)
+            if (int e = run_block(m, pl, b, s)) return e;
+    }
+    hipLaunchKernelGGL(k_output, dim3(pl->B), dim3(64), 0, s, pl->h, pl->x, pl->x0, pl->n_nodes, pl->node_off, pl->N,
+                       m->out_w, m->out_b, out);
+    MCG_HIP(hipGetLastError());
+    return MCG_OK;
+}
+
+// Kernel-level pin: run ONE EquivariantBlock on compact state (egnn.py:188-222).
+// h_io[M][420], x_io[M][3], x0[M][3] are dense compact arrays on the device.
+int mcg_egnn_block_debug(const mcg_egnn* m, mcg_plan* pl, int block, float* h_io, float* x_io, const float* x0,
+                         void* stream) {
+    if (!m || !pl || block < 0 || block >= m->n_blocks) return MCG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    MCG_HIP(hipMemsetAsync(pl->h, 0, (size_t)pl->M * HP * sizeof(float), s));
+    MCG_HIP(hipMemsetAsync(pl->x, 0, (size_t)pl->M * 4 * sizeof(float), s));
+    MCG_HIP(hipMemsetAsync(pl->x0, 0, (size_t)pl->M * 4 * sizeof(float), s));
+    MCG_HIP(hipMemcpy2DAsync(pl->h, HP * sizeof(float), h_io, H * sizeof(float), H * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));
+    MCG_HIP(hipMemcpy2DAsync(pl->x, 4 * sizeof(float), x_io, 3 * sizeof(float), 3 * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));
+    MCG_HIP(hipMemcpy2DAsync(pl->x0, 4 * sizeof(float), x0, 3 * sizeof(float), 3 * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));
+    if (int e = run_block(m, pl, block, s)) return e;
+    MCG_HIP(hipMemcpy2DAsync(h_io, H * sizeof(float), pl->h, HP * sizeof(float), H * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));
+    MCG_HIP(hipMemcpy2DAsync(x_io, 3 * sizeof(float), pl->x, 4 * sizeof(float), 3 * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));
+    return MCG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,159 @@
+"""EGNN denoiser behind the reference's operator seam (egnn.py:448-541 `EGNNDynamics`).
+
+`EGNNDynamics.forward(t, xh, node_mask, edge_mask, context)` keeps the 5-tensor
+contract of the reference (and of its ONNX export, onnx_export_utils.py:38-49);
+the arithmetic runs in libmlconfgen_hip.so.  Weights are handed over in the
+reference's state-dict layout and repacked by the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from .config import EGNN_HIDDEN, EGNN_N_BLOCKS
+from .weights import edm_spec
+
+
+class BatchPlan:
+    """Batch geometry (molecule sizes -> compact node/edge tiling) + device workspace.
+    Replaces the reference's per-call `get_adj_matrix` and mask tensors."""
+
+    def __init__(self, n_nodes: torch.Tensor, max_n_nodes: int, device: torch.device, edge_mt: int = 0):
+        L = _lib.lib()
+        n_host = n_nodes.detach().to("cpu", torch.int32).contiguous().reshape(-1)
+        self.B = int(n_host.numel())
+        self.N = int(max_n_nodes)
+        self.device = torch.device(device)
+        self.n_nodes_host = n_host
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(L.mcg_plan_create(self.B, self.N, n_host.data_ptr(), int(edge_mt), C.byref(self._h)),
+                       "mcg_plan_create")
+        info = torch.zeros(8, dtype=torch.int32)
+        _lib.check(L.mcg_plan_info(self._h, info.data_ptr()), "mcg_plan_info")
+        (self.n_real_nodes, self.n_real_edges, self.edge_mt, self.n_edge_waves, self.n_pslots, _, _,
+         self.n_edge_tiles) = [int(v) for v in info]
+
+    @property
+    def handle(self):
+        return self._h
+
+    def node_mask(self) -> torch.Tensor:
+        idx = torch.arange(self.N).unsqueeze(0)
+        return (idx < self.n_nodes_host.unsqueeze(1)).to(torch.float32).unsqueeze(2).to(self.device)
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().mcg_plan_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+def sizes_from_node_mask(node_mask: torch.Tensor) -> torch.Tensor:
+    """n_nodes[B] from a [B,N,1] (or [B,N]) prefix mask; rejects non-prefix masks (the
+    reference only ever builds prefix masks, mol_utils.py:241-243)."""
+    nm = node_mask.reshape(node_mask.shape[0], -1)
+    n = nm.sum(1).round().to(torch.int64)
+    expect = (torch.arange(nm.shape[1], device=nm.device).unsqueeze(0) < n.unsqueeze(1)).to(nm.dtype)
+    if not bool(torch.equal(nm, expect)):
+        raise ValueError("node_mask must be a 0/1 prefix mask per sample (as built by prepare_masks)")
+    return n.to("cpu", torch.int32)
+
+
+class EGNNDynamics(torch.nn.Module):
+    def __init__(self, in_node_nf: int = 9, context_node_nf: int = 3, n_dims: int = 3,
+                 hidden_nf: int = EGNN_HIDDEN, device: torch.device = torch.device("cuda:0"),
+                 normalization_factor: float = 100.0, n_blocks: int = EGNN_N_BLOCKS):
+        super().__init__()
+        if hidden_nf != EGNN_HIDDEN or in_node_nf != 9 or context_node_nf != 3 or n_dims != 3 \
+                or normalization_factor != 100.0:
+            raise ValueError("the HIP kernels are specialised for the published architecture "
+                             "(in_node_nf=9, context_node_nf=3, hidden_nf=420, normalization 100)")
+        self.in_node_nf, self.context_node_nf, self.n_dims = in_node_nf, context_node_nf, n_dims
+        self.hidden_nf, self.n_blocks = hidden_nf, n_blocks
+        self.device = torch.device(device)
+        self._h = C.c_void_p()
+        self._plans: Dict[tuple, BatchPlan] = {}
+
+    # -- weights ------------------------------------------------------------------
+    def load_reference_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "dynamics.egnn.") -> None:
+        """Accepts the keys of the reference checkpoint."""
+        L = _lib.lib()
+        spec = edm_spec(self.hidden_nf, self.in_node_nf + self.context_node_nf, self.n_blocks)
+        tensors = []
+        for key, shape, _, _ in spec:
+            k = prefix + key[len("dynamics.egnn."):]
+            if k not in sd:
+                raise RuntimeError(f"Missing key(s) in state_dict: \"{k}\"")
+            t = sd[k].detach().to("cpu", torch.float32).contiguous()
+            if tuple(t.shape) != tuple(shape):
+                raise RuntimeError(f"size mismatch for {k}: {tuple(t.shape)} vs {tuple(shape)}")
+            tensors.append(t)
+        arr = _lib.host_ptr_array(tensors)
+        if self._h:
+            L.mcg_egnn_destroy(self._h)
+            self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(L.mcg_egnn_create(arr, len(tensors), self.hidden_nf, self.n_blocks, C.byref(self._h)),
+                       "mcg_egnn_create")
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise _lib.McgError("EGNNDynamics has no weights loaded")
+        return self._h
+
+    # -- plans --------------------------------------------------------------------
+    def plan(self, n_nodes: torch.Tensor, max_n_nodes: int, edge_mt: int = 0) -> BatchPlan:
+        key = (int(max_n_nodes), int(edge_mt), tuple(int(v) for v in n_nodes.reshape(-1).tolist()))
+        p = self._plans.get(key)
+        if p is None:
+            if len(self._plans) >= 4:
+                self._plans.pop(next(iter(self._plans)))
+            p = BatchPlan(n_nodes, max_n_nodes, self.device, edge_mt)
+            self._plans[key] = p
+        return p
+
+    # -- operator seam ------------------------------------------------------------
+    def run(self, plan: BatchPlan, t: torch.Tensor, xh: torch.Tensor, context: torch.Tensor,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        L = _lib.lib()
+        if out is None:
+            out = torch.empty_like(xh)
+        _lib.check(L.mcg_egnn_dynamics(self.handle, plan.handle, _lib.dptr(t), _lib.dptr(xh), _lib.dptr(context),
+                                       _lib.dptr(out), _lib.current_stream_ptr(self.device)), "mcg_egnn_dynamics")
+        return out
+
+    @torch.no_grad()
+    def forward(self, t, xh, node_mask, edge_mask, context):
+        """out[B,N,11] - same contract as the reference (egnn.py:472-513).  `edge_mask`
+        is accepted for interface parity; it is fully determined by `node_mask`."""
+        B, N, _ = xh.shape
+        plan = self.plan(sizes_from_node_mask(node_mask), N)
+        f32 = dict(device=self.device, dtype=torch.float32)
+        return self.run(plan, t.reshape(B).to(**f32).contiguous(), xh.to(**f32).contiguous(),
+                        context.to(**f32).contiguous())
+
+    def block_debug(self, plan: BatchPlan, block: int, h: torch.Tensor, x: torch.Tensor, x0: torch.Tensor):
+        """One EquivariantBlock on compact arrays (kernel-level parity pin)."""
+        L = _lib.lib()
+        h = h.to(self.device, torch.float32).contiguous().clone()
+        x = x.to(self.device, torch.float32).contiguous().clone()
+        x0 = x0.to(self.device, torch.float32).contiguous()
+        _lib.check(L.mcg_egnn_block_debug(self.handle, plan.handle, int(block), _lib.dptr(h), _lib.dptr(x),
+                                          _lib.dptr(x0), _lib.current_stream_ptr(self.device)), "mcg_egnn_block_debug")
+        return h, x
+
+    def __del__(self):
+        try:
+            self._plans.clear()
+            if self._h:
+                _lib.lib().mcg_egnn_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:  # noqa: BLE001
+            pass
