@@ -54,6 +54,17 @@ int mcg_egnn_dynamics(const mcg_egnn* m, mcg_plan* p, const float* t, const floa
 int mcg_egnn_block_debug(const mcg_egnn* m, mcg_plan* p, int block, float* h_io, float* x_io, const float* x0,
                          void* stream);
 
+/* Debug hooks: one GCL layer (egnn.py:70-85) on compact arrays (result stays in the plan), and a
+ * copy-out of the plan's internal buffers: which = 0 h[M][432], 1 pab[M][864], 2 agg[M][432],
+ * 3 node-MLP hidden[M][432], 4 x[M][4]. */
+int mcg_egnn_gcl_debug(const mcg_egnn* m, mcg_plan* p, int layer, const float* h_in, const float* x_in,
+                       const float* x0, void* stream);
+int mcg_plan_peek(const mcg_plan* p, int which, float* dst, void* stream);
+
+/* Measurement hook: the edge-MLP kernel of GCL layer `layer` (equiv = 0, 0..2*n_blocks-1) or of the
+ * coordinate update of block `layer` (equiv = 1) launched `iters` times on the plan's current state. */
+int mcg_bench_edge(const mcg_egnn* m, mcg_plan* p, int layer, int equiv, int iters, void* stream);
+
 /* ---- Sampler arithmetic (equivariant_diffusion.py).  randn_x[B,N,3] / randn_h[B,N,8] are RAW
  * standard-normal draws (the caller draws them in the reference's order: x first, then h);
  * masking and centre-of-gravity removal (:56-76) happen inside. */

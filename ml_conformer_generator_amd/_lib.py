@@ -26,6 +26,9 @@ SIGNATURES: Dict[str, tuple] = {
     "mcg_plan_info": (_i, [_vp, _vp]),
     "mcg_egnn_dynamics": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mcg_egnn_block_debug": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "mcg_egnn_gcl_debug": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "mcg_plan_peek": (_i, [_vp, _i, _vp, _vp]),
+    "mcg_bench_edge": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "mcg_sampler_noise": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mcg_sampler_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp]),
     "mcg_sampler_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),

@@ -42,11 +42,19 @@ __host__ __device__ inline int mcg_kperm(int step, int g, int K) {
     return 16 * (K / 16) + 4 * (step - full) + g;   // tail: 4 consecutive k per step
 }
 
-__device__ __forceinline__ float mcg_silu(float x) {
-    // x * sigmoid(x); v_exp_f32 / v_rcp_f32 (~1 ulp each)
-    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+#ifndef MCG_PRECISE
+#define MCG_PRECISE 0
+#endif
+__device__ __forceinline__ float mcg_sigmoid(float x) {
+#if MCG_PRECISE == 2
+    return 1.0f / (1.0f + expf(-x));
+#elif MCG_PRECISE == 1
+    return 1.0f / (1.0f + __expf(-x));
+#else
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));      // v_exp_f32 / v_rcp_f32 (~1 ulp each)
+#endif
 }
-__device__ __forceinline__ float mcg_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float mcg_silu(float x) { return x * mcg_sigmoid(x); }
 
 __device__ __forceinline__ f32x4 mcg_mfma(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);

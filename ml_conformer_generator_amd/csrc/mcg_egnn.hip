@@ -69,7 +69,7 @@ struct EdgeArgs {
     const float* x0;        // [M_r][4] coordinates at network input (d0)
     const float* wd;        // [HP] layer-1 weights of d2 (current squared distance)
     const float* wd0;       // [HP] layer-1 weights of d0 (initial squared distance)
-    const float* Bp;        // packed second-layer weights (KSTEPS x NT x 64)
+    const float* Bp;        // packed second-layer weights (KSTEPS x NT x 64, + 1 KB pad)
     const float* b2;        // [HP]
     const float* wv;        // [HP] attention weights (GCL) or coordinate head w5 (equiv)
     float bv;               // attention bias (GCL)
@@ -77,26 +77,25 @@ struct EdgeArgs {
     const int* tile_mol;    // molecule of the first row of every 16-row tile
     const int* wave_nf;     // first compact node touched by each wave
     const int* wave_poff;   // prefix offsets of (wave, node) partial slots
-    int n_rows; int n_mtiles;
+    int n_rows; int n_mtiles; int n_waves;
     float* P;               // GCL: [n_pslots][HP] partial sums;  equiv: [n_pslots][4]
 };
 
-template <int MT, bool EQUIV>
-__global__ __launch_bounds__(64) void k_edge(EdgeArgs p) {
-    const int lane = threadIdx.x;
-    const int g = lane >> 4, c = lane & 15;
-    const int wave = blockIdx.x;
-    const int nf = p.wave_nf[wave];
-
-    // ---- decode this lane's A-operand rows (row = tile*16 + c)
+template <int MT>
+struct RowInfo {            // per-lane facts about its A-operand rows (row = tile*16 + (lane & 15))
     int ni[MT], nj[MT], seg[MT];
     float d2[MT], d02[MT], ux[MT], uy[MT], uz[MT];
+};
+
+template <int MT, bool EQUIV>
+__device__ __forceinline__ void edge_decode(const EdgeArgs& p, int wave, bool live, int c, RowInfo<MT>& R) {
+    const int nf = p.wave_nf[wave];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int tile = wave * MT + mt;
         const int r = tile * 16 + c;
         int vi = 0, vj = 0, sg = -1;
-        if (tile < p.n_mtiles && r < p.n_rows) {
+        if (live && tile < p.n_mtiles && r < p.n_rows) {
             int b = p.tile_mol[tile];
             while (r >= p.row_off[b + 1]) ++b;
             const int n = p.n_nodes[b];
@@ -108,82 +107,29 @@ __global__ __launch_bounds__(64) void k_edge(EdgeArgs p) {
             vj = p.node_off[b] + j;
             sg = vi - nf;
         }
-        ni[mt] = vi; nj[mt] = vj; seg[mt] = sg;
+        R.ni[mt] = vi; R.nj[mt] = vj; R.seg[mt] = sg;
         const f32x4 xi = *reinterpret_cast<const f32x4*>(p.x + (size_t)vi * 4);
         const f32x4 xj = *reinterpret_cast<const f32x4*>(p.x + (size_t)vj * 4);
         const f32x4 yi = *reinterpret_cast<const f32x4*>(p.x0 + (size_t)vi * 4);
         const f32x4 yj = *reinterpret_cast<const f32x4*>(p.x0 + (size_t)vj * 4);
         const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
         const float ex = yi[0] - yj[0], ey = yi[1] - yj[1], ez = yi[2] - yj[2];
-        d2[mt] = dx * dx + dy * dy + dz * dz;            // coord2diff radial (egnn.py:410-411)
-        d02[mt] = ex * ex + ey * ey + ez * ez;
+        R.d2[mt] = dx * dx + dy * dy + dz * dz;            // coord2diff radial (egnn.py:410-411)
+        R.d02[mt] = ex * ex + ey * ey + ez * ez;
         if (EQUIV) {
-            const float inv = 1.0f / sqrtf(d2[mt] + 1e-8f);  // egnn.py:412-413
-            ux[mt] = dx * inv; uy[mt] = dy * inv; uz[mt] = dz * inv;
+            const float inv = 1.0f / sqrtf(R.d2[mt] + 1e-8f);  // egnn.py:412-413
+            R.ux[mt] = dx * inv; R.uy[mt] = dy * inv; R.uz[mt] = dz * inv;
+        } else {
+            R.ux[mt] = R.uy[mt] = R.uz[mt] = 0.f;
         }
     }
+}
 
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const float* pa[MT];
-    const float* pb[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        pa[mt] = p.pab + (size_t)ni[mt] * (2 * HP) + 4 * g;
-        pb[mt] = p.pab + (size_t)nj[mt] * (2 * HP) + HP + 4 * g;
-    }
-    const float* bp = p.Bp + lane;
-
-    // ---- main loop: 26 groups of 16 k  (k = 16q + 4g + s)
-#pragma unroll 1
-    for (int q = 0; q < H / 16; ++q) {
-        const f32x4 wdv = *reinterpret_cast<const f32x4*>(p.wd + 16 * q + 4 * g);
-        const f32x4 w0v = *reinterpret_cast<const f32x4*>(p.wd0 + 16 * q + 4 * g);
-        f32x4 a4[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 va = *reinterpret_cast<const f32x4*>(pa[mt] + 16 * q);
-            const f32x4 vb = *reinterpret_cast<const f32x4*>(pb[mt] + 16 * q);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float pre = fmaf(w0v[s], d02[mt], fmaf(wdv[s], d2[mt], va[s] + vb[s]));
-                a4[mt][s] = mcg_silu(pre);
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float b = bp[nt * 64];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mcg_mfma(a4[mt][s], b, acc[mt][nt]);
-            }
-            bp += NT * 64;
-        }
-    }
-    {   // tail k-step: k = 416 + g
-        const int k = (H / 16) * 16 + g;
-        const float wdk = p.wd[k], w0k = p.wd0[k];
-        float a1[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const float va = p.pab[(size_t)ni[mt] * (2 * HP) + k];
-            const float vb = p.pab[(size_t)nj[mt] * (2 * HP) + HP + k];
-            a1[mt] = mcg_silu(fmaf(w0k, d02[mt], fmaf(wdk, d2[mt], va + vb)));
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float b = bp[nt * 64];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mcg_mfma(a1[mt], b, acc[mt][nt]);
-        }
-    }
-
-    // ---- epilogue.  C/D layout: column = 16*nt + c, row = 4*g + r of tile mt.
+// Epilogue shared by both edge kernels.  C/D layout: column = 16*nt + c, row = 4*g + r of tile mt.
+template <int MT, bool EQUIV>
+__device__ __forceinline__ void edge_epilogue(const EdgeArgs& p, int wave, bool live, int lane, f32x4 (&acc)[MT][NT],
+                                              const RowInfo<MT>& R) {
+    const int g = lane >> 4, c = lane & 15;
     float part[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -211,17 +157,17 @@ __global__ __launch_bounds__(64) void k_edge(EdgeArgs p) {
         for (int r = 0; r < 4; ++r) {
             const float dot = mcg_row16_sum(part[mt][r]);
             const int src = 4 * g + r;                    // lane whose A-row is this C-row
-            rseg[mt][r] = __shfl(seg[mt], src, 64);
+            rseg[mt][r] = __shfl(R.seg[mt], src, 64);
             if (EQUIV) {
                 // trans = coord_diff * phi * edge_mask (egnn.py:124-127)
-                tx[mt][r] = __shfl(ux[mt], src, 64) * dot;
-                ty[mt][r] = __shfl(uy[mt], src, 64) * dot;
-                tz[mt][r] = __shfl(uz[mt], src, 64) * dot;
+                tx[mt][r] = __shfl(R.ux[mt], src, 64) * dot;
+                ty[mt][r] = __shfl(R.uy[mt], src, 64) * dot;
+                tz[mt][r] = __shfl(R.uz[mt], src, 64) * dot;
             } else {
                 scale[mt][r] = mcg_sigmoid(dot + p.bv);   // att_mlp (egnn.py:36,48)
             }
         }
-
+    if (!live) return;
     const int nseg = p.wave_poff[wave + 1] - p.wave_poff[wave];
     const int pbase = p.wave_poff[wave];
     if (EQUIV) {
@@ -258,6 +204,215 @@ __global__ __launch_bounds__(64) void k_edge(EdgeArgs p) {
             }
         }
     }
+}
+
+// ---- v1: one independent wave per workgroup, B fragments straight from global/L2 ------------
+template <int MT, bool EQUIV>
+__global__ __launch_bounds__(64) void k_edge(EdgeArgs p) {
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, c = lane & 15;
+    const int wave = blockIdx.x;
+    RowInfo<MT> R;
+    edge_decode<MT, EQUIV>(p, wave, true, c, R);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* pa[MT];
+    const float* pb[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        pa[mt] = p.pab + (size_t)R.ni[mt] * (2 * HP) + 4 * g;
+        pb[mt] = p.pab + (size_t)R.nj[mt] * (2 * HP) + HP + 4 * g;
+    }
+    const float* bp = p.Bp + lane;
+
+    // ---- main loop: 26 groups of 16 k  (k = 16q + 4g + s)
+#pragma unroll 1
+    for (int q = 0; q < H / 16; ++q) {
+        const f32x4 wdv = *reinterpret_cast<const f32x4*>(p.wd + 16 * q + 4 * g);
+        const f32x4 w0v = *reinterpret_cast<const f32x4*>(p.wd0 + 16 * q + 4 * g);
+        f32x4 a4[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 va = *reinterpret_cast<const f32x4*>(pa[mt] + 16 * q);
+            const f32x4 vb = *reinterpret_cast<const f32x4*>(pb[mt] + 16 * q);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float pre = fmaf(w0v[s], R.d02[mt], fmaf(wdv[s], R.d2[mt], va[s] + vb[s]));
+                a4[mt][s] = mcg_silu(pre);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float b = bp[nt * 64];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mcg_mfma(a4[mt][s], b, acc[mt][nt]);
+            }
+            bp += NT * 64;
+        }
+    }
+    {   // tail k-step: k = 416 + g
+        const int k = (H / 16) * 16 + g;
+        const float wdk = p.wd[k], w0k = p.wd0[k];
+        float a1[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float va = p.pab[(size_t)R.ni[mt] * (2 * HP) + k];
+            const float vb = p.pab[(size_t)R.nj[mt] * (2 * HP) + HP + k];
+            a1[mt] = mcg_silu(fmaf(w0k, R.d02[mt], fmaf(wdk, R.d2[mt], va + vb)));
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float b = bp[nt * 64];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mcg_mfma(a1[mt], b, acc[mt][nt]);
+        }
+    }
+    edge_epilogue<MT, EQUIV>(p, wave, true, lane, acc, R);
+}
+
+// ---- v2: 4 waves per workgroup share the packed W2 through LDS --------------------------------
+// W2 is streamed global -> LDS with the asynchronous LDS-DMA (global_load_lds, 16 B/lane, no VGPR
+// round trip) one 16-k group (4 MFMA k-steps x 27 column tiles = 27 KB) ahead of the MFMAs that
+// consume it, double-buffered; each wave reads its B fragments back with conflict-free
+// ds_read_b32 (the B-pack line order IS the lane order).  L2 traffic for W2 drops 4x and the
+// load latency no longer sits in front of the matrix pipe.
+constexpr int GROUP_FLOATS = 4 * NT * 64;          // 6912 floats = 27 KiB: one 16-k group of B-pack
+constexpr int GROUP_LDS_FLOATS = 28 * 256;         // 7 x 1 KiB pieces per wave x 4 waves = 28 KiB
+
+template <int MT, bool EQUIV>
+__global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * GROUP_LDS_FLOATS];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int wave_raw = blockIdx.x * 4 + wid;
+    const bool live = wave_raw < p.n_waves;
+    const int wave = live ? wave_raw : p.n_waves - 1;
+    RowInfo<MT> R;
+    edge_decode<MT, EQUIV>(p, wave, live, c, R);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* pa[MT];
+    const float* pb[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        pa[mt] = p.pab + (size_t)R.ni[mt] * (2 * HP) + 4 * g;
+        pb[mt] = p.pab + (size_t)R.nj[mt] * (2 * HP) + HP + 4 * g;
+    }
+    const float* wdp = p.wd + 4 * g;
+    const float* w0p = p.wd0 + 4 * g;
+
+    // stage group q of the B-pack into LDS buffer `buf`: 7 x 1 KiB pieces per wave
+    auto stage = [&](int q, int buf) {
+        const float* src = p.Bp + (size_t)q * GROUP_FLOATS + lane * 4;
+        float* dst = lds + buf * GROUP_LDS_FLOATS;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int piece = wid + 4 * i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 256),
+                                             (__attribute__((address_space(3))) void*)(dst + piece * 256), 16, 0, 0);
+        }
+    };
+    auto agen = [&](const f32x4 (&va)[MT], const f32x4 (&vb)[MT], const f32x4& wdv, const f32x4& w0v, f32x4 (&a4)[MT]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                a4[mt][s] = mcg_silu(fmaf(w0v[s], R.d02[mt], fmaf(wdv[s], R.d2[mt], va[mt][s] + vb[mt][s])));
+    };
+
+    // prologue: B group 0 in flight, A operand of group 0 generated
+    stage(0, 0);
+    f32x4 a4[MT];
+    {
+        f32x4 va[MT], vb[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            va[mt] = *reinterpret_cast<const f32x4*>(pa[mt]);
+            vb[mt] = *reinterpret_cast<const f32x4*>(pb[mt]);
+        }
+        const f32x4 wdv = *reinterpret_cast<const f32x4*>(wdp);
+        const f32x4 w0v = *reinterpret_cast<const f32x4*>(w0p);
+        agen(va, vb, wdv, w0v, a4);
+    }
+
+    constexpr int NG = H / 16;      // 26 full groups, then one tail k-step (k = 416 + g)
+#pragma unroll 1
+    for (int q = 0; q < NG; ++q) {
+        const int buf = q & 1;
+        asm volatile("s_barrier" ::: "memory");                    // (A) buffer buf^1 is free again
+        // A-operand inputs of the NEXT group (or of the tail step) - ordinary loads, issued first
+        f32x4 va[MT], vb[MT], wdv, w0v;
+        if (q + 1 < NG) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                va[mt] = *reinterpret_cast<const f32x4*>(pa[mt] + 16 * (q + 1));
+                vb[mt] = *reinterpret_cast<const f32x4*>(pb[mt] + 16 * (q + 1));
+            }
+            wdv = *reinterpret_cast<const f32x4*>(wdp + 16 * (q + 1));
+            w0v = *reinterpret_cast<const f32x4*>(w0p + 16 * (q + 1));
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                va[mt] = (f32x4){p.pab[(size_t)R.ni[mt] * (2 * HP) + 16 * NG + g], 0.f, 0.f, 0.f};
+                vb[mt] = (f32x4){p.pab[(size_t)R.nj[mt] * (2 * HP) + HP + 16 * NG + g], 0.f, 0.f, 0.f};
+            }
+            wdv = (f32x4){p.wd[16 * NG + g], 0.f, 0.f, 0.f};
+            w0v = (f32x4){p.wd0[16 * NG + g], 0.f, 0.f, 0.f};
+        }
+        stage(q + 1, buf ^ 1);                                     // group q+1 (the tail group when q+1 == NG)
+        // my pieces of group q have landed once at most the loads issued above are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 + 2 * MT + 2) : "memory");
+        asm volatile("s_barrier" ::: "memory");                    // (B) everybody's pieces of group q landed
+        const float* lb = lds + buf * GROUP_LDS_FLOATS + lane;
+        f32x4 a4n[MT];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float b = lb[(s * NT + nt) * 64];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mcg_mfma(a4[mt][s], b, acc[mt][nt]);
+            }
+            if (s == 1) {
+                // The next group's A operand is generated HERE: its loads were issued two k-steps
+                // (~1.7k cycles of MFMA work) ago.  The scheduling fences keep hipcc from hoisting
+                // this block up against the loads (which would expose their full latency).
+                // (an empty asm makes the loaded registers opaque until this point: pure arithmetic
+                // on them is otherwise free to float above the barriers, right behind the loads)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(va[mt]), "+v"(vb[mt]));
+                asm volatile("" : "+v"(wdv), "+v"(w0v));
+                agen(va, vb, wdv, w0v, a4n);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a4[mt] = a4n[mt];
+    }
+    {   // tail k-step from buffer NG & 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        const float* lb = lds + (NG & 1) * GROUP_LDS_FLOATS + lane;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float b = lb[nt * 64];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mcg_mfma(a4[mt][0], b, acc[mt][nt]);
+        }
+    }
+    edge_epilogue<MT, EQUIV>(p, wave, live, lane, acc, R);
 }
 
 // agg[v] = (sum of the per-wave partials that cover node v) / 100   (egnn.py:429-435)
@@ -357,9 +512,9 @@ __global__ __launch_bounds__(64) void k_output(const float* __restrict__ h, cons
 
 // ------------------------------------------------------------------------------ host: packing
 template <class F>
-void pack_B(std::vector<float>& dst, int K, int n_tiles, F value /* (n, k) -> W */) {
+void pack_B(std::vector<float>& dst, int K, int n_tiles, F value /* (n, k) -> W */, int pad_floats = 0) {
     const int steps = K / 4;
-    dst.assign((size_t)steps * n_tiles * 64, 0.f);
+    dst.assign((size_t)steps * n_tiles * 64 + pad_floats, 0.f);
     for (int st = 0; st < steps; ++st)
         for (int nt = 0; nt < n_tiles; ++nt)
             for (int l = 0; l < 64; ++l) {
@@ -433,7 +588,8 @@ int build_edge_layer(mcg_egnn* m, EdgeLayer& L, const float* w1 /*[420][842]*/, 
     for (int n = 0; n < H; ++n) v[n] = w1[(size_t)n * (2 * H + 2) + 2 * H + 1];   // initial d2 column
     if (int e = upload(v, &L.wd0)) return e;
     m->allocs.push_back(L.wd0);
-    pack_B(buf, H, NT, [&](int n, int k) -> float { return n < H ? w2[(size_t)n * H + k] : 0.f; });
+    // + one LDS group of padding: the staged tail group over-reads up to 28 KiB (k_edge_lds)
+    pack_B(buf, H, NT, [&](int n, int k) -> float { return n < H ? w2[(size_t)n * H + k] : 0.f; }, GROUP_LDS_FLOATS);
     if (int e = upload(buf, &L.w2_Bp)) return e;
     m->allocs.push_back(L.w2_Bp);
     v.assign(HP, 0.f);
@@ -470,8 +626,20 @@ int build_node_layer(mcg_egnn* m, NodeLayer& L, const float* w3 /*[420][840]*/, 
     return MCG_OK;
 }
 
+int g_edge_variant = -1;   // 0: v1 (direct global B), 1: v2 (LDS-staged B); env MCG_EDGE_KERNEL
+
 template <int MT>
 void launch_edge(bool equiv, const EdgeArgs& a, int n_waves, hipStream_t s) {
+    if (g_edge_variant < 0) {
+        const char* e = getenv("MCG_EDGE_KERNEL");
+        g_edge_variant = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    if (g_edge_variant == 1) {
+        const int wgs = (n_waves + 3) / 4;
+        if (equiv) hipLaunchKernelGGL((k_edge_lds<MT, true>), dim3(wgs), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_edge_lds<MT, false>), dim3(wgs), dim3(256), 0, s, a);
+        return;
+    }
     if (equiv) hipLaunchKernelGGL((k_edge<MT, true>), dim3(n_waves), dim3(64), 0, s, a);
     else hipLaunchKernelGGL((k_edge<MT, false>), dim3(n_waves), dim3(64), 0, s, a);
 }
@@ -482,7 +650,7 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
     a.pab = pl->pab; a.x = pl->x; a.x0 = pl->x0; a.wd = L.wd; a.wd0 = L.wd0; a.Bp = L.w2_Bp; a.b2 = L.b2;
     a.wv = L.wv; a.bv = L.bv; a.n_nodes = pl->n_nodes; a.node_off = pl->node_off; a.row_off = pl->row_off;
     a.B = pl->B; a.tile_mol = pl->tile_mol; a.wave_nf = pl->wave_nf; a.wave_poff = pl->wave_poff;
-    a.n_rows = pl->n_rows; a.n_mtiles = pl->n_mtiles; a.P = P;
+    a.n_rows = pl->n_rows; a.n_mtiles = pl->n_mtiles; a.n_waves = pl->n_waves; a.P = P;
     switch (pl->MT) {
         case 1: launch_edge<1>(equiv, a, pl->n_waves, s); break;
         case 2: launch_edge<2>(equiv, a, pl->n_waves, s); break;
@@ -709,6 +877,47 @@ int mcg_egnn_dynamics(const mcg_egnn* m, mcg_plan* pl, const float* t, const flo
                        m->out_w, m->out_b, out);
     MCG_HIP(hipGetLastError());
     return MCG_OK;
+}
+
+// Measurement hook: launch the edge kernel of one layer `iters` times back-to-back on the plan's
+// current state (bench.py brackets this with events on the same stream for the roofline figure).
+int mcg_bench_edge(const mcg_egnn* m, mcg_plan* pl, int layer, int equiv, int iters, void* stream) {
+    if (!m || !pl || iters < 1 || layer < 0 || layer >= (equiv ? m->n_blocks : 2 * m->n_blocks)) return MCG_ERR_ARG;
+    for (int i = 0; i < iters; ++i)
+        if (int e = run_edge(pl, equiv ? m->equiv[layer] : m->gcl_edge[layer], equiv != 0, equiv ? pl->Px : pl->P,
+                             (hipStream_t)stream)) return e;
+    return MCG_OK;
+}
+
+// Debug/test hooks: run ONE GCL layer on the plan's current compact state (after block_debug-style
+// upload) and copy internal buffers out.  which: 0 h[M][432], 1 pab[M][864], 2 agg[M][432],
+// 3 t1[M][432], 4 x[M][4]
+int mcg_plan_peek(const mcg_plan* pl, int which, float* dst, void* stream) {
+    if (!pl || !dst) return MCG_ERR_ARG;
+    const float* src = nullptr; size_t n = 0;
+    switch (which) {
+        case 0: src = pl->h; n = (size_t)pl->M * HP; break;
+        case 1: src = pl->pab; n = (size_t)pl->M * 2 * HP; break;
+        case 2: src = pl->agg; n = (size_t)pl->M * HP; break;
+        case 3: src = pl->t1; n = (size_t)pl->M * HP; break;
+        case 4: src = pl->x; n = (size_t)pl->M * 4; break;
+        default: return MCG_ERR_ARG;
+    }
+    MCG_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MCG_OK;
+}
+
+int mcg_egnn_gcl_debug(const mcg_egnn* m, mcg_plan* pl, int layer, const float* h_in, const float* x_in,
+                       const float* x0, void* stream) {
+    if (!m || !pl || layer < 0 || layer >= 2 * m->n_blocks) return MCG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    MCG_HIP(hipMemsetAsync(pl->h, 0, (size_t)pl->M * HP * sizeof(float), s));
+    MCG_HIP(hipMemsetAsync(pl->x, 0, (size_t)pl->M * 4 * sizeof(float), s));
+    MCG_HIP(hipMemsetAsync(pl->x0, 0, (size_t)pl->M * 4 * sizeof(float), s));
+    MCG_HIP(hipMemcpy2DAsync(pl->h, HP * sizeof(float), h_in, H * sizeof(float), H * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));
+    MCG_HIP(hipMemcpy2DAsync(pl->x, 4 * sizeof(float), x_in, 3 * sizeof(float), 3 * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));
+    MCG_HIP(hipMemcpy2DAsync(pl->x0, 4 * sizeof(float), x0, 3 * sizeof(float), 3 * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));
+    return run_gcl(m, pl, layer, s);
 }
 
 // Kernel-level pin: run ONE EquivariantBlock on compact state (egnn.py:188-222).

@@ -104,6 +104,30 @@ def test_dynamics_edge_tilings_agree_with_oracle(dyn, edm_sd, mt):
     assert ok, f"err {err} scale {sc}"
 
 
+def test_dynamics_full_gain_weights_vs_oracle():
+    """Unit-gain synthetic weights (messages / aggregates are O(1), so every operand of the node
+    MLP carries weight in the result) on a ragged batch, against the oracle."""
+    from ml_conformer_generator_amd import weights as W
+    from ml_conformer_generator_amd.egnn import EGNNDynamics
+    from oracle import egnn_oracle as EO
+    from oracle import host_oracle as HO
+    sd = W.synth_edm_state_dict(99, weight_gain=1.0, coord_out_gain=0.2)
+    d = EGNNDynamics(device=DEV)
+    d.load_reference_state_dict(sd)
+    torch.manual_seed(8)
+    sizes = torch.tensor([17, 33, 15, 26])
+    N = 33
+    nm, em = HO.masks_from_sizes(sizes, N)
+    z = torch.randn(4, N, 11) * nm
+    ctx = torch.randn(4, 1, 3).repeat(1, N, 1) * nm
+    t = torch.full((4, 1), 0.25)
+    ref = EO.egnn_dynamics(sd, t, z, nm, em, ctx)
+    out = d(t.to(DEV), z.to(DEV), nm.to(DEV), em.to(DEV), ctx.to(DEV))
+    ok, err, sc = close(out, ref)
+    assert ok, f"err {err} scale {sc}"
+    assert sc > 0.5
+
+
 def test_small_fragments_and_degenerate_sizes(dyn, edm_sd):
     """n = 1 (no edges), n = 2, n = 7 (fragment generation sizes) next to a large molecule."""
     from oracle import egnn_oracle as EO

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks on the GPU box: edge kernel per launch, one full denoiser call (phi).
+Usage: python tools/bench_kernels.py [--shape c2|c3] [--mt 0|1|2]   (MCG_EDGE_KERNEL=0/1 selects v1/v2)"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ml_conformer_generator_amd import _lib, weights as W
+from ml_conformer_generator_amd.egnn import EGNNDynamics
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--shape", default="c2")
+ap.add_argument("--mt", type=int, default=0)
+ap.add_argument("--iters", type=int, default=20)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+dyn = EGNNDynamics(device=dev)
+dyn.load_reference_state_dict(W.synth_edm_state_dict(1234))
+if a.shape == "c2":
+    sizes = torch.full((64,), 27, dtype=torch.int32); N = 27
+else:
+    torch.manual_seed(7); sizes = torch.randint(15, 40, (256,)).to(torch.int32); N = 39
+plan = dyn.plan(sizes, N, edge_mt=a.mt)
+B = sizes.numel()
+z = torch.randn(B, N, 11, device=dev); ctx = torch.zeros(B, N, 3, device=dev); t = torch.full((B,), 0.5, device=dev)
+out = dyn.run(plan, t, z, ctx)
+L = _lib.lib(); st = _lib.current_stream_ptr(dev)
+def timed(fn, iters):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); fn_iters = fn(iters) if False else [fn() for _ in range(iters)]; e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+ms_edge = timed(lambda: L.mcg_bench_edge(dyn.handle, plan.handle, 4, 0, 10, st), 5) / 10
+ms_eq = timed(lambda: L.mcg_bench_edge(dyn.handle, plan.handle, 4, 1, 10, st), 5) / 10
+ms_phi = timed(lambda: dyn.run(plan, t, z, ctx, out), a.iters)
+E = plan.n_real_edges
+fl = 2.0 * E * (420 * 420 + 3 * 420)
+print(f"shape={a.shape} variant={os.environ.get('MCG_EDGE_KERNEL','1')} mt={plan.edge_mt} waves={plan.n_edge_waves} E={E} M={plan.n_real_nodes} "
+      f"edge_gcl={ms_edge*1e3:.1f}us ({fl/ms_edge/1e9:.1f} TF/s) edge_equiv={ms_eq*1e3:.1f}us phi={ms_phi:.3f}ms")
