@@ -569,8 +569,9 @@ namespace {
 int build_edge_layer(mcg_egnn* m, EdgeLayer& L, const float* w1 /*[420][842]*/, const float* b1, const float* w2,
                      const float* b2, const float* wv, float bv) {
     std::vector<float> buf;
-    // (Wa | Wb): 54 column tiles over K = 420
-    pack_B(buf, H, 2 * NT, [&](int n, int k) -> float {
+    // (Wa | Wb): 54 column tiles over K = 420   (B-pack4: consumed by the row-block GEMM)
+    buf.clear();
+    mcg_pack_b4(buf, H, 2 * NT, [&](int n, int k) -> float {
         if (n < HP) return n < H ? w1[(size_t)n * (2 * H + 2) + k] : 0.f;
         const int nn = n - HP;
         return nn < H ? w1[(size_t)nn * (2 * H + 2) + H + k] : 0.f;
@@ -606,18 +607,18 @@ int build_edge_layer(mcg_egnn* m, EdgeLayer& L, const float* w1 /*[420][842]*/, 
 
 int build_node_layer(mcg_egnn* m, NodeLayer& L, const float* w3 /*[420][840]*/, const float* b3, const float* w4,
                      const float* b4) {
-    std::vector<float> buf, seg2;
-    // two K segments: [h | agg]  (egnn.py:66)
-    pack_B(buf, H, NT, [&](int n, int k) -> float { return n < H ? w3[(size_t)n * (2 * H) + k] : 0.f; });
-    pack_B(seg2, H, NT, [&](int n, int k) -> float { return n < H ? w3[(size_t)n * (2 * H) + H + k] : 0.f; });
-    buf.insert(buf.end(), seg2.begin(), seg2.end());
+    std::vector<float> buf;
+    // two K segments: [h | agg]  (egnn.py:66), each a B-pack4
+    mcg_pack_b4(buf, H, NT, [&](int n, int k) -> float { return n < H ? w3[(size_t)n * (2 * H) + k] : 0.f; });
+    mcg_pack_b4(buf, H, NT, [&](int n, int k) -> float { return n < H ? w3[(size_t)n * (2 * H) + H + k] : 0.f; });
     if (int e = upload(buf, &L.w3_Bp)) return e;
     m->allocs.push_back(L.w3_Bp);
     std::vector<float> v(HP, 0.f);
     for (int n = 0; n < H; ++n) v[n] = b3[n];
     if (int e = upload(v, &L.b3)) return e;
     m->allocs.push_back(L.b3);
-    pack_B(buf, H, NT, [&](int n, int k) -> float { return n < H ? w4[(size_t)n * H + k] : 0.f; });
+    buf.clear();
+    mcg_pack_b4(buf, H, NT, [&](int n, int k) -> float { return n < H ? w4[(size_t)n * H + k] : 0.f; });
     if (int e = upload(buf, &L.w4_Bp)) return e;
     m->allocs.push_back(L.w4_Bp);
     for (int n = 0; n < H; ++n) v[n] = b4[n];
@@ -789,15 +790,10 @@ int mcg_plan_create(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_
     p->M = node_off[B];
     p->n_rows = row_off[B];
     p->n_mtiles = (p->n_rows + 15) / 16;
-    // rows per wave: minimise (rounds over the 1024 SIMDs) x (tiles per wave); ties -> larger tile
+    // rows per wave: 16 (MT = 1) keeps the LDS-staged edge kernel at 2 workgroups per CU (2 waves per
+    // SIMD cover each other's barrier / epilogue bubbles); measured faster than MT = 2 at configs 2 and 3.
+    // MT = 2, 3 stay selectable for experiments (MT = 3 needs 324 accumulators: hipcc spills it).
     int best = 1;
-    long best_cost = -1;
-    // (MT = 3 needs 324 accumulator registers: hipcc spills it - kept for experiments only)
-    for (int mt = 1; mt <= 2; ++mt) {
-        const long waves = (p->n_mtiles + mt - 1) / mt;
-        const long cost = ((waves + 1023) / 1024) * mt;
-        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = mt; }
-    }
     if (edge_mt >= 1 && edge_mt <= 3) best = edge_mt;
     if (const char* e = getenv("MCG_EDGE_MT")) { const int v = atoi(e); if (v >= 1 && v <= 3) best = v; }
     p->MT = best;

@@ -111,17 +111,11 @@ int up(const std::vector<float>& v, float** d, std::vector<void*>& allocs) {
 
 int build_lin(Lin& L, const float* w, const float* b, int n_out, int k_in, int k_pad, std::vector<void*>& allocs) {
     L.K = k_pad; L.n_out = n_out; L.n_tiles = (n_out + 15) / 16;
-    const int steps = k_pad / 4;
-    std::vector<float> buf((size_t)steps * L.n_tiles * 64, 0.f);
-    for (int st = 0; st < steps; ++st)
-        for (int l = 0; l < 64; ++l) {
-            const int k = mcg_kperm(st, l >> 4, k_pad);
-            if (k >= k_in) continue;
-            for (int nt = 0; nt < L.n_tiles; ++nt) {
-                const int n = nt * 16 + (l & 15);
-                if (n < n_out) buf[((size_t)st * L.n_tiles + nt) * 64 + l] = w[(size_t)n * k_in + k];
-            }
-        }
+    std::vector<float> buf;
+    const int n_tiles = L.n_tiles;
+    mcg_pack_b4(buf, k_pad, n_tiles, [&](int n, int k) -> float {
+        return (n < n_out && k < k_in) ? w[(size_t)n * k_in + k] : 0.f;
+    });
     if (int e = up(buf, &L.Bp, allocs)) return e;
     std::vector<float> bb((size_t)L.n_tiles * 16, 0.f);
     for (int n = 0; n < n_out; ++n) bb[n] = b[n];

@@ -1,19 +1,28 @@
-// Row-tile GEMM on v_mfma_f32_16x16x4_f32 for the node-side contractions of the EGNN
+// Row-block GEMM on v_mfma_f32_16x16x4_f32 for the node-side contractions of the EGNN
 // and the Linear layers of the GCN:
-//     C[M, n_out] = epilogue( [A1 | A2][M, K1+K2] * Bp + bias ) (+ residual)
-// One wave owns a 16-row x (16*NTW)-column output tile; a 256-thread workgroup holds
-// 4 waves on 4 consecutive 16-row tiles of the SAME column block, so the packed-B lines
-// they stream are shared through the CU's L1.  A rows are read straight from global
-// (16-byte loads, 4 k-steps per load - see mcg_common.h for the k permutation).
+//     C[M, n_out] = epilogue( [A1 | A2][M, K1+K2] * Bp4 + bias ) (+ residual)
+// A 256-thread workgroup owns 32 rows x (4 waves x RN column tiles); each wave keeps a
+// 2 x RN grid of 16x16 accumulators.  Operands come straight from global memory with
+// 16-byte loads, register double-buffered one 16-k group ahead of the MFMAs: the four
+// waves of a workgroup read the SAME 32 A rows (shared through the CU's L1) and disjoint
+// packed-B columns.  No LDS, no barriers.
+//
+// "B-pack4" layout of a weight W[n_out][K] (nn.Linear layout), per K segment:
+//   full 16-k groups:  Bp4[((q * n_tiles + nt) * 64 + lane) * 4 + s] = W[16 nt + (lane&15)][16 q + 4 (lane>>4) + s]
+//   then tail steps:   Bp4[tail_base + (st * n_tiles + nt) * 64 + lane] = W[16 nt + (lane&15)][16 Q + 4 st + (lane>>4)]
+// i.e. one 16-byte load gives a lane its B operand for the 4 k-steps of a group, matching
+// the 16-byte load of 4 consecutive k of its A row (k permutation: mcg_common.h).
 #pragma once
 #include "mcg_common.h"
+
+#include <vector>
 
 enum { MCG_ACT_NONE = 0, MCG_ACT_SILU = 1, MCG_ACT_RELU = 2 };
 
 struct McgGemmArgs {
     const float* A1; int lda1; int K1;      // first K segment  (K1 % 4 == 0)
     const float* A2; int lda2; int K2;      // optional second segment (concat along K), K2 may be 0
-    const float* Bp;                        // packed weights: (K1/4 + K2/4) steps x n_tiles x 64
+    const float* Bp;                        // B-pack4 of segment 1 followed by B-pack4 of segment 2
     const float* bias;                      // [n_tiles*16] (padded) or nullptr
     const float* resid; int ldr;            // optional residual added after activation
     float* C; int ldc;
@@ -21,90 +30,167 @@ struct McgGemmArgs {
     int act;
 };
 
-template <int NTW>
+// floats occupied by one K segment of a B-pack4
+__host__ __device__ static inline size_t mcg_pack4_floats(int K, int n_tiles) { return (size_t)(K / 4) * n_tiles * 64; }
+
+template <class F>
+static void mcg_pack_b4(std::vector<float>& dst, int K, int n_tiles, F value /* (n, k) -> W[n][k] or 0 */) {
+    const size_t base = dst.size();
+    dst.resize(base + mcg_pack4_floats(K, n_tiles), 0.f);
+    const int groups = K / 16, tail = (K - groups * 16) / 4;
+    float* d = dst.data() + base;
+    for (int q = 0; q < groups; ++q)
+        for (int nt = 0; nt < n_tiles; ++nt)
+            for (int l = 0; l < 64; ++l)
+                for (int s = 0; s < 4; ++s)
+                    d[(((size_t)q * n_tiles + nt) * 64 + l) * 4 + s] = value(nt * 16 + (l & 15), 16 * q + 4 * (l >> 4) + s);
+    float* t = d + (size_t)groups * n_tiles * 256;
+    for (int st = 0; st < tail; ++st)
+        for (int nt = 0; nt < n_tiles; ++nt)
+            for (int l = 0; l < 64; ++l)
+                t[((size_t)st * n_tiles + nt) * 64 + l] = value(nt * 16 + (l & 15), 16 * groups + 4 * st + (l >> 4));
+}
+
+template <int RN>
 __global__ __launch_bounds__(256) void mcg_gemm_kernel(McgGemmArgs p) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wid = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
-    const int mtile = blockIdx.x * 4 + wave;
-    const int nt0 = blockIdx.y * NTW;
-    if (mtile * 16 >= p.M) return;
-    const int row = mtile * 16 + c;                 // A-operand row of this lane
-    const int rowc = row < p.M ? row : p.M - 1;     // clamp (results of padded rows are dropped)
-
-    f32x4 acc[NTW];
+    // waves are numbered linearly over (row block, wave column) so that the grid is exactly
+    // ceil(waves / 4) workgroups - a 2-D grid rounds each row block up to whole workgroups and
+    // can push a 243-workgroup problem over the 256-CU edge into a second round.
+    const int wave_cols = (p.n_tiles + RN - 1) / RN;
+    const int wlin = blockIdx.x * 4 + wid;
+    if (wlin >= ((p.M + 31) / 32) * wave_cols) return;
+    const int row0 = (wlin / wave_cols) * 32;
+    const int nt0 = (wlin % wave_cols) * RN;
+    int rA[2];
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < 2; ++m) {
+        const int r = row0 + 16 * m + c;
+        rA[m] = r < p.M ? r : p.M - 1;          // clamp: results of padded rows are dropped
+    }
+    bool nvalid[RN];
+    int ncl[RN];            // column-tile offset clamped into range (results of invalid tiles are dropped)
+#pragma unroll
+    for (int n = 0; n < RN; ++n) {
+        nvalid[n] = nt0 + n < p.n_tiles;
+        ncl[n] = nvalid[n] ? n : 0;
+    }
 
-    int step_base = 0;
+    f32x4 acc[2][RN];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < RN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* bseg = p.Bp;
 #pragma unroll 1
     for (int seg = 0; seg < 2; ++seg) {
         const float* A = seg == 0 ? p.A1 : p.A2;
         const int K = seg == 0 ? p.K1 : p.K2;
         const int lda = seg == 0 ? p.lda1 : p.lda2;
         if (K == 0) continue;
-        const float* arow = A + (size_t)rowc * lda;
+        const float* a0 = A + (size_t)rA[0] * lda + 4 * g;
+        const float* a1 = A + (size_t)rA[1] * lda + 4 * g;
         const int groups = K / 16;
-        const float* bp = p.Bp + ((size_t)step_base * p.n_tiles + nt0) * 64 + lane;
-        const size_t bstride = (size_t)p.n_tiles * 64;
-#pragma unroll 2
-        for (int q = 0; q < groups; ++q) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 16 * q + 4 * g);
+        const size_t gstride = (size_t)p.n_tiles * 256;
+        const float* bq = bseg + (size_t)nt0 * 256 + lane * 4;
+        if (groups == 0) goto tail_steps;
+        {
+
+        // 3-deep register ring: the loads of group q+3 are issued right after group q's MFMAs
+        // and are consumed two compute blocks (>= 1k cycles of MFMA work) later - there is
+        // less than one wave per SIMD on the small node GEMMs, so latency is hidden by ILP.
+        f32x4 Ar[3][2], Br[3][RN];
+        // loads are UNCONDITIONAL (group index and column tile clamped): a runtime "load or zero"
+        // select makes hipcc branch around every load and drain vmcnt(0) behind it.
+        auto load_group = [&](int slot, int q) {
+            q = q < groups ? q : groups - 1;
+            Ar[slot][0] = *reinterpret_cast<const f32x4*>(a0 + 16 * q);
+            Ar[slot][1] = *reinterpret_cast<const f32x4*>(a1 + 16 * q);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int n = 0; n < RN; ++n)
+                Br[slot][n] = *reinterpret_cast<const f32x4*>(bq + (size_t)q * gstride + ncl[n] * 256);
+        };
+        auto compute = [&](int slot) {
 #pragma unroll
-                for (int i = 0; i < NTW; ++i) {
-                    const float b = (nt0 + i < p.n_tiles) ? bp[(size_t)i * 64] : 0.f;
-                    acc[i] = mcg_mfma(a4[s], b, acc[i]);
-                }
-                bp += bstride;
-            }
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < RN; ++n) acc[m][n] = mcg_mfma(Ar[slot][m][s], Br[slot][n][s], acc[m][n]);
+        };
+        load_group(0, 0); load_group(1, 1); load_group(2, 2);
+        // branch-free body (control flow inside the loop makes hipcc's wait-count pass fall back to
+        // vmcnt(0) at the loop head, draining the ring); the <= 2 leftover groups are peeled.
+        int q = 0;
+#pragma unroll 1
+        for (; q + 3 <= groups; q += 3) {
+            // sched_barrier pins "MFMAs of group q | loads of group q+3": left alone, hipcc clusters all
+            // 15 loads at the loop bottom and the first MFMA block then waits for every one of them.
+            compute(0); __builtin_amdgcn_sched_barrier(0); load_group(0, q + 3); __builtin_amdgcn_sched_barrier(0);
+            compute(1); __builtin_amdgcn_sched_barrier(0); load_group(1, q + 4); __builtin_amdgcn_sched_barrier(0);
+            compute(2); __builtin_amdgcn_sched_barrier(0); load_group(2, q + 5); __builtin_amdgcn_sched_barrier(0);
         }
+        if (q < groups) compute(0);
+        if (q + 1 < groups) compute(1);
+        }
+    tail_steps:
         const int tail = (K - groups * 16) / 4;
-        for (int s = 0; s < tail; ++s) {
-            const float a = arow[groups * 16 + 4 * s + g];
+        const float* bt = bseg + (size_t)groups * gstride + (size_t)nt0 * 64 + lane;
+        for (int st = 0; st < tail; ++st) {
+            const float av0 = a0[groups * 16 + 4 * st - 4 * g + g];   // k = 16Q + 4st + g
+            const float av1 = a1[groups * 16 + 4 * st - 4 * g + g];
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) {
-                const float b = (nt0 + i < p.n_tiles) ? bp[(size_t)i * 64] : 0.f;
-                acc[i] = mcg_mfma(a, b, acc[i]);
+            for (int n = 0; n < RN; ++n) {
+                const float b = bt[(size_t)st * p.n_tiles * 64 + ncl[n] * 64];
+                acc[0][n] = mcg_mfma(av0, b, acc[0][n]);
+                acc[1][n] = mcg_mfma(av1, b, acc[1][n]);
             }
-            bp += bstride;
         }
-        step_base += K / 4;
+        bseg += mcg_pack4_floats(K, p.n_tiles);
     }
 
     // epilogue: C/D layout  col = lane & 15, row = 4*(lane>>4) + r
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-        const int nt = nt0 + i;
-        if (nt >= p.n_tiles) break;
-        const int col = nt * 16 + c;
+    for (int n = 0; n < RN; ++n) {
+        if (!nvalid[n]) continue;
+        const int col = (nt0 + n) * 16 + c;
         if (col >= p.n_store) continue;
         const float bias = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int orow = mtile * 16 + 4 * g + r;
-            if (orow >= p.M) continue;
-            float v = acc[i][r] + bias;
-            if (p.act == MCG_ACT_SILU) v = mcg_silu(v);
-            else if (p.act == MCG_ACT_RELU) v = fmaxf(v, 0.f);
-            if (p.resid) v += p.resid[(size_t)orow * p.ldr + col];
-            p.C[(size_t)orow * p.ldc + col] = v;
-        }
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int orow = row0 + 16 * m + 4 * g + r;
+                if (orow >= p.M) continue;
+                float v = acc[m][n][r] + bias;
+                if (p.act == MCG_ACT_SILU) v = mcg_silu(v);
+                else if (p.act == MCG_ACT_RELU) v = fmaxf(v, 0.f);
+                if (p.resid) v += p.resid[(size_t)orow * p.ldr + col];
+                p.C[(size_t)orow * p.ldc + col] = v;
+            }
     }
 }
 
 static inline hipError_t mcg_gemm_launch(const McgGemmArgs& a, hipStream_t s) {
-    const int mtiles = (a.M + 15) / 16;
-    if (mtiles == 0) return hipSuccess;
-    // pick the column-block width so that the grid has >= ~4 waves per SIMD where possible
-    const int rowblocks = (mtiles + 3) / 4;
-    int ntw = 4;
-    if ((long)rowblocks * ((a.n_tiles + 3) / 4) < 512) ntw = 2;
-    if ((long)rowblocks * ((a.n_tiles + 1) / 2) < 512) ntw = 1;
-    dim3 grid(rowblocks, (a.n_tiles + ntw - 1) / ntw);
-    if (ntw == 4) hipLaunchKernelGGL(mcg_gemm_kernel<4>, grid, dim3(256), 0, s, a);
-    else if (ntw == 2) hipLaunchKernelGGL(mcg_gemm_kernel<2>, grid, dim3(256), 0, s, a);
+    if (a.M <= 0) return hipSuccess;
+    const int rowblocks = (a.M + 31) / 32;
+    // wave tile width RN in {1,2,3}: minimise (rounds of 256 four-wave workgroups) x (work per wave ~ RN);
+    // ties go to the wider tile (fewer redundant A loads)
+    int rn = 1;
+    long best = -1;
+    for (int cand = 1; cand <= 3; ++cand) {
+        const long waves = (long)rowblocks * ((a.n_tiles + cand - 1) / cand);
+        const long wgs = (waves + 3) / 4;
+        const long cost = ((wgs + 255) / 256) * cand;
+        if (best < 0 || cost <= best) { best = cost; rn = cand; }
+    }
+    const long waves = (long)rowblocks * ((a.n_tiles + rn - 1) / rn);
+    dim3 grid((unsigned)((waves + 3) / 4));
+    if (rn == 3) hipLaunchKernelGGL(mcg_gemm_kernel<3>, grid, dim3(256), 0, s, a);
+    else if (rn == 2) hipLaunchKernelGGL(mcg_gemm_kernel<2>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(mcg_gemm_kernel<1>, grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
