@@ -285,6 +285,7 @@ __global__ __launch_bounds__(64) void k_edge(EdgeArgs p) {
 // load latency no longer sits in front of the matrix pipe.
 constexpr int GROUP_FLOATS = 4 * NT * 64;          // 6912 floats = 27 KiB: one 16-k group of B-pack
 constexpr int GROUP_LDS_FLOATS = 28 * 256;         // 7 x 1 KiB pieces per wave x 4 waves = 28 KiB
+constexpr int PD = 6;                              // depth of the B-fragment register ring
 
 template <int MT, bool EQUIV>
 __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p) {
@@ -314,15 +315,20 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
     const float* wdp = p.wd + 4 * g;
     const float* w0p = p.wd0 + 4 * g;
 
-    // stage group q of the B-pack into LDS buffer `buf`: 7 x 1 KiB pieces per wave
+    // stage group q of the B-pack into LDS buffer `buf`: 7 x 1 KiB pieces per wave.  MUBUF
+    // (buffer_load ... lds) rather than global_load_lds: hipcc treats the latter as a FLAT access
+    // that may touch LDS and then forces every lgkmcnt wait to 0 while one is pending, which
+    // serialises the ds_read ring below for half of every group.  Out-of-range reads of the
+    // padded last group return 0 through the descriptor's bounds check.
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.Bp), 0, (KSTEPS * NT * 64 + GROUP_LDS_FLOATS) * 4, 0x00020000);
     auto stage = [&](int q, int buf) {
-        const float* src = p.Bp + (size_t)q * GROUP_FLOATS + lane * 4;
         float* dst = lds + buf * GROUP_LDS_FLOATS;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             const int piece = wid + 4 * i;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 256),
-                                             (__attribute__((address_space(3))) void*)(dst + piece * 256), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(brsrc, (__attribute__((address_space(3))) void*)(dst + piece * 256), 16,
+                                                 lane * 16, (q * GROUP_FLOATS + piece * 256) * 4, 0, 0);
         }
     };
     auto agen = [&](const f32x4 (&va)[MT], const f32x4 (&vb)[MT], const f32x4& wdv, const f32x4& w0v, f32x4 (&a4)[MT]) {
@@ -378,20 +384,29 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
         asm volatile("s_barrier" ::: "memory");                    // (B) everybody's pieces of group q landed
         const float* lb = lds + buf * GROUP_LDS_FLOATS + lane;
         f32x4 a4n[MT];
+        // B fragments go through a PD-deep register ring: the ds_read of fragment i+PD is issued
+        // right behind the MFMA(s) of fragment i, so LDS latency hides under PD*MT MFMAs of the SAME
+        // wave (left alone hipcc emits "ds_read; s_waitcnt lgkmcnt(0); 2 MFMAs" back to back).
+        float bq[PD];
+#pragma unroll
+        for (int i = 0; i < PD; ++i) bq[i] = lb[i * 64];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const float b = lb[(s * NT + nt) * 64];
+                const int idx = s * NT + nt;
+                const float b = bq[idx % PD];
+                if (idx + PD < 4 * NT) bq[idx % PD] = lb[(idx + PD) * 64];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mcg_mfma(a4[mt][s], b, acc[mt][nt]);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);     // MT MFMAs
             }
             if (s == 1) {
                 // The next group's A operand is generated HERE: its loads were issued two k-steps
-                // (~1.7k cycles of MFMA work) ago.  The scheduling fences keep hipcc from hoisting
-                // this block up against the loads (which would expose their full latency).
-                // (an empty asm makes the loaded registers opaque until this point: pure arithmetic
-                // on them is otherwise free to float above the barriers, right behind the loads)
+                // (~1.7k cycles of MFMA work) ago.  An empty asm makes the loaded registers opaque until
+                // this point: pure arithmetic on them is otherwise free to float above the barriers,
+                // right behind the loads (which exposes their full latency).
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(va[mt]), "+v"(vb[mt]));
                 asm volatile("" : "+v"(wdv), "+v"(w0v));
