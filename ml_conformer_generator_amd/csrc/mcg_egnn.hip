@@ -472,16 +472,16 @@ __global__ void k_coord_update(const float* __restrict__ Px, const int* __restri
 // ------------------------------------------------------------------------------ output head
 // h_final = embedding_out(h) (first 8 of 12 channels kept), vel = (x - x0) with the masked
 // mean removed; padded slots of out[B,N,11] are zero  (egnn.py:398-399, :499-513).
-__global__ __launch_bounds__(64) void k_output(const float* __restrict__ h, const float* __restrict__ x,
-                                                const float* __restrict__ x0, const int* __restrict__ n_nodes,
-                                                const int* __restrict__ node_off, int N,
-                                                const float* __restrict__ out_w,  // [12][HP]
-                                                const float* __restrict__ out_b, float* __restrict__ out) {
+__global__ __launch_bounds__(512) void k_output(const float* __restrict__ h, const float* __restrict__ x,
+                                                 const float* __restrict__ x0, const int* __restrict__ n_nodes,
+                                                 const int* __restrict__ node_off, int N,
+                                                 const float* __restrict__ out_w,  // [12][HP]
+                                                 const float* __restrict__ out_b, float* __restrict__ out) {
     const int b = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int n = n_nodes[b];
     const int v0 = node_off[b];
-    // masked mean of the velocity
+    // masked mean of the velocity (every wave computes it: n <= N lanes' worth of work)
     float sx = 0.f, sy = 0.f, sz = 0.f;
     for (int i = lane; i < n; i += 64) {
         sx += x[(size_t)(v0 + i) * 4 + 0] - x0[(size_t)(v0 + i) * 4 + 0];
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(64) void k_output(const float* __restrict__ h, cons
     const float inv_n = n > 0 ? 1.0f / (float)n : 0.f;
     const float mx = sx * inv_n, my = sy * inv_n, mz = sz * inv_n;
     float* ob = out + (size_t)b * N * 11;
-    for (int i = 0; i < N; ++i) {
+    for (int i = wid; i < N; i += 8) {          // one wave per node slot
         float* o = ob + (size_t)i * 11;
         if (i >= n) {
             if (lane < 11) o[lane] = 0.f;
@@ -884,7 +884,7 @@ int mcg_egnn_dynamics(const mcg_egnn* m, mcg_plan* pl, const float* t, const flo
         for (int b = 0; b < m->n_blocks; ++b)
             if (int e = run_block(m, pl, b, s)) return e;
     }
-    hipLaunchKernelGGL(k_output, dim3(pl->B), dim3(64), 0, s, pl->h, pl->x, pl->x0, pl->n_nodes, pl->node_off, pl->N,
+    hipLaunchKernelGGL(k_output, dim3(pl->B), dim3(512), 0, s, pl->h, pl->x, pl->x0, pl->n_nodes, pl->node_off, pl->N,
                        m->out_w, m->out_b, out);
     MCG_HIP(hipGetLastError());
     return MCG_OK;

@@ -8,6 +8,7 @@ the GPU box (`backend="nccl"`), gloo in the CPU tests.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Tuple
 
 import torch
@@ -38,8 +39,8 @@ def gather_results(local: Dict[str, torch.Tensor], n_samples: int, group=None) -
     if not dist.is_available() or not dist.is_initialized():
         return local
     world = dist.get_world_size(group)
-    if world == 1:
-        return local
+    if world == 1 and not os.environ.get("MCG_FORCE_COLLECTIVE"):
+        return local          # (MCG_FORCE_COLLECTIVE=1: run the collective on a 1-rank group - RCCL smoke check)
     sizes = shard_sizes(n_samples, world)
     cap = max(sizes)
     out = {}
