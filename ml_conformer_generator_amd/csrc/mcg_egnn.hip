@@ -185,23 +185,28 @@ __device__ __forceinline__ void edge_epilogue(const EdgeArgs& p, int wave, bool 
             }
         }
     } else {
-        for (int s = 0; s < nseg; ++s) {
-            float w[MT][4];
+        // Segmented, gate-scaled sum over the tile's 16 rows ON THE MATRIX PIPE:
+        //   D[seg][col] = sum_row S[seg][row] * m[row][col],   S[seg][row] = (seg(row) == seg) ? att(row) : 0
+        // With the contraction index ordered (t, g) <-> row 4g + t, the B operand of k-step t is exactly the
+        // C/D register acc[.][nt][t] this lane already holds, and the A operand is built from the row facts
+        // it already holds (seg index = lane & 15).  4 MFMAs per column tile replace a per-segment loop of
+        // masked FMAs + cross-lane shuffles, for any number of segments up to 16 per tile.
+        float sel[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sel[mt][r] = rseg[mt][r] == c ? scale[mt][r] : 0.f;   // m * att * edge_mask
+        const int row_seg = 4 * g;                     // D rows held by this lane: segments 4g .. 4g+3
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) w[mt][r] = rseg[mt][r] == s ? scale[mt][r] : 0.f;
-            float* dst = p.P + (size_t)(pbase + s) * HP + c;
+                for (int t = 0; t < 4; ++t) d = mcg_mfma(sel[mt][t], acc[mt][nt][t], d);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                float v = 0.f;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v = fmaf(acc[mt][nt][r], w[mt][r], v);   // m * att * edge_mask
-                v = mcg_group4_sum(v);
-                if (g == 0) dst[nt * 16] = v;
-            }
+            for (int r = 0; r < 4; ++r)
+                if (row_seg + r < nseg) p.P[(size_t)(pbase + row_seg + r) * HP + nt * 16 + c] = d[r];
         }
     }
 }
@@ -286,6 +291,9 @@ __global__ __launch_bounds__(64) void k_edge(EdgeArgs p) {
 constexpr int GROUP_FLOATS = 4 * NT * 64;          // 6912 floats = 27 KiB: one 16-k group of B-pack
 constexpr int GROUP_LDS_FLOATS = 28 * 256;         // 7 x 1 KiB pieces per wave x 4 waves = 28 KiB
 constexpr int PD = 6;                              // depth of the B-fragment register ring
+#ifndef MCG_ABLATE
+#define MCG_ABLATE 0   // measurement builds only: 1 skip epilogue, 2 skip A-gen, 4 skip LDS staging + barriers
+#endif
 
 template <int MT, bool EQUIV>
 __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p) {
@@ -358,7 +366,9 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
 #pragma unroll 1
     for (int q = 0; q < NG; ++q) {
         const int buf = q & 1;
+#if !(MCG_ABLATE & 4)
         asm volatile("s_barrier" ::: "memory");                    // (A) buffer buf^1 is free again
+#endif
         // A-operand inputs of the NEXT group (or of the tail step) - ordinary loads, issued first
         f32x4 va[MT], vb[MT], wdv, w0v;
         if (q + 1 < NG) {
@@ -378,10 +388,12 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
             wdv = (f32x4){p.wd[16 * NG + g], 0.f, 0.f, 0.f};
             w0v = (f32x4){p.wd0[16 * NG + g], 0.f, 0.f, 0.f};
         }
+#if !(MCG_ABLATE & 4)
         stage(q + 1, buf ^ 1);                                     // group q+1 (the tail group when q+1 == NG)
         // my pieces of group q have landed once at most the loads issued above are outstanding
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 + 2 * MT + 2) : "memory");
         asm volatile("s_barrier" ::: "memory");                    // (B) everybody's pieces of group q landed
+#endif
         const float* lb = lds + buf * GROUP_LDS_FLOATS + lane;
         f32x4 a4n[MT];
         // B fragments go through a PD-deep register ring: the ds_read of fragment i+PD is issued
@@ -410,7 +422,12 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(va[mt]), "+v"(vb[mt]));
                 asm volatile("" : "+v"(wdv), "+v"(w0v));
+#if (MCG_ABLATE & 2)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a4n[mt] = va[mt] + vb[mt] + wdv + w0v;
+#else
                 agen(va, vb, wdv, w0v, a4n);
+#endif
             }
         }
 #pragma unroll
@@ -427,7 +444,18 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
             for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mcg_mfma(a4[mt][0], b, acc[mt][nt]);
         }
     }
+#if (MCG_ABLATE & 1)
+    {
+        float sink = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) sink += acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2] + acc[mt][nt][3];
+        if (sink == 123.456f) p.P[0] = sink;
+    }
+#else
     edge_epilogue<MT, EQUIV>(p, wave, live, lane, acc, R);
+#endif
 }
 
 // agg[v] = (sum of the per-wave partials that cover node v) / 100   (egnn.py:429-435)
@@ -577,6 +605,13 @@ struct mcg_plan {
     float *x = nullptr, *x0 = nullptr, *h = nullptr, *h2 = nullptr, *pab = nullptr, *agg = nullptr, *t1 = nullptr,
           *P = nullptr, *Px = nullptr;
     std::vector<void*> allocs;
+    // optional split into independent molecule ranges that run on separate HIP streams
+    // (the latency-bound node GEMMs of one range overlap the edge kernels of the other)
+    std::vector<mcg_plan*> subs;
+    std::vector<int> sub_b0;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> ev_join;
+    hipEvent_t ev_fork = nullptr;
 };
 
 namespace {
@@ -784,7 +819,7 @@ void mcg_egnn_destroy(mcg_egnn* m) {
     delete m;
 }
 
-int mcg_plan_create(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_plan** out) {
+static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_plan** out) {
     if (B < 1 || N < 1 || !n_nodes_host || !out) {
         mcg_set_error("mcg_plan_create: bad arguments");
         return MCG_ERR_ARG;
@@ -861,8 +896,47 @@ int mcg_plan_create(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_
 
 void mcg_plan_destroy(mcg_plan* p) {
     if (!p) return;
+    for (mcg_plan* q : p->subs) mcg_plan_destroy(q);
+    for (hipStream_t st : p->streams) (void)hipStreamDestroy(st);
+    for (hipEvent_t e : p->ev_join) (void)hipEventDestroy(e);
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     for (void* q : p->allocs) (void)hipFree(q);
     delete p;
+}
+
+int mcg_plan_create(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_plan** out) {
+    if (int e = plan_create_single(B, N, n_nodes_host, edge_mt, out)) return e;
+    mcg_plan* p = *out;
+    // Split the batch into `parts` molecule ranges of ~equal edge count, one HIP stream each.
+    // Measured (tools/bench_kernels.py): 2 ranges are 7 % faster at config 3 (12 k edge tiles = 12 rounds
+    // of the chip) but 12 % slower at config 2 (2.8 k tiles: halving them wrecks the tile quantisation),
+    // so the split is only taken when every range still fills the chip several times over.
+    int parts = p->n_mtiles >= 8192 ? 2 : 1;
+    if (const char* e = getenv("MCG_SPLIT")) parts = atoi(e);
+    if (parts < 2 || B < 2 * parts || p->n_rows < 4096) return MCG_OK;
+    std::vector<long> cum(B + 1, 0);
+    for (int b = 0; b < B; ++b) cum[b + 1] = cum[b] + (long)n_nodes_host[b] * (n_nodes_host[b] > 0 ? n_nodes_host[b] - 1 : 0);
+    int b0 = 0;
+    for (int k = 0; k < parts; ++k) {
+        int b1 = B;
+        if (k + 1 < parts) {
+            const long target = cum[B] * (k + 1) / parts;
+            b1 = b0 + 1;
+            while (b1 < B && cum[b1] < target) ++b1;
+        }
+        mcg_plan* sub = nullptr;
+        if (int e = plan_create_single(b1 - b0, N, n_nodes_host + b0, edge_mt, &sub)) { mcg_plan_destroy(p); return e; }
+        p->subs.push_back(sub);
+        p->sub_b0.push_back(b0);
+        hipStream_t st; hipEvent_t ev;
+        MCG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        MCG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        p->streams.push_back(st);
+        p->ev_join.push_back(ev);
+        b0 = b1;
+    }
+    MCG_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    return MCG_OK;
 }
 
 int mcg_plan_info(const mcg_plan* p, int32_t* info /*[8]*/) {
@@ -877,6 +951,19 @@ int mcg_egnn_dynamics(const mcg_egnn* m, mcg_plan* pl, const float* t, const flo
                       float* out, void* stream) {
     if (!m || !pl || !t || !xh || !context || !out) { mcg_set_error("mcg_egnn_dynamics: null argument"); return MCG_ERR_ARG; }
     hipStream_t s = (hipStream_t)stream;
+    if (!pl->subs.empty()) {
+        // fork: every molecule range runs the whole denoiser on its own stream, join back on `s`
+        MCG_HIP(hipEventRecord(pl->ev_fork, s));
+        for (size_t k = 0; k < pl->subs.size(); ++k) {
+            const size_t b0 = (size_t)pl->sub_b0[k];
+            MCG_HIP(hipStreamWaitEvent(pl->streams[k], pl->ev_fork, 0));
+            if (int e = mcg_egnn_dynamics(m, pl->subs[k], t + b0, xh + b0 * pl->N * 11, context + b0 * pl->N * 3,
+                                          out + b0 * pl->N * 11, (void*)pl->streams[k])) return e;
+            MCG_HIP(hipEventRecord(pl->ev_join[k], pl->streams[k]));
+            MCG_HIP(hipStreamWaitEvent(s, pl->ev_join[k], 0));
+        }
+        return MCG_OK;
+    }
     if (pl->M > 0) {
         hipLaunchKernelGGL(k_prep_embed, dim3(pl->M), dim3(128), 0, s, xh, t, context, pl->node_mol, pl->node_off, pl->N,
                            m->emb_wT, m->emb_b, pl->h, pl->x, pl->x0);

@@ -347,3 +347,24 @@ def test_generator_end_to_end_c1(edm_sd, gcn_sd):
         gen.generate_conformers(reference_context=torch.tensor([50.0, 100.0, 130.0]))
     with pytest.raises(ValueError):
         gen.generate_conformers()
+
+
+@pytest.mark.parametrize("ifm", [False, True])
+def test_generator_fixed_fragment_modes(edm_sd, gcn_sd, ifm):
+    """Plumbing of both fixed-fragment strategies (inpaint / inertial fragment matching + merge) on the HIP path:
+    the fragment's atom types survive where the reference pins them, shapes and counts are right."""
+    from ml_conformer_generator_amd import MLConformerGenerator
+    g = load_golden("ifm_front_end.npz")
+    gen = MLConformerGenerator(diffusion_steps=12, device=DEV, edm_weights=edm_sd, adj_mat_seer_weights=gcn_sd)
+    frag = (g["frag_x"], g["frag_z"].tolist())
+    torch.manual_seed(3)
+    x, h, nm = gen.edm_tensors(g["ref_context"], n_samples=3, min_n_nodes=21, max_n_nodes=25, resample_steps=1,
+                               fixed_fragment=frag, inertial_fragment_matching=ifm, blend_power=3,
+                               ifm_diffusion_level=5)
+    assert x.shape == (3, 25, 3) and h.shape == (3, 25, 8) and torch.isfinite(x).all()
+    n = nm.sum(1).reshape(-1)
+    assert int(n.min()) >= 21 and int(n.max()) <= 25
+    assert float((h.sum(2) - nm.squeeze(2)).abs().max()) == 0.0            # one-hot on real atoms, zero on padding
+    with pytest.raises(IndexError):                                         # level > steps, as the reference
+        gen.edm_tensors(g["ref_context"], n_samples=2, min_n_nodes=21, max_n_nodes=25, fixed_fragment=frag,
+                        inertial_fragment_matching=True, ifm_diffusion_level=50)

@@ -132,3 +132,30 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+def test_inertial_fragment_matching_front_end_matches_reference():
+    """ifm_prepare_gen_fragment_context / inverse_coord_transform /
+    ifm_prepare_fragments_for_merge / shift_moi_to_com_batch against reference outputs."""
+    g = load_golden("ifm_front_end.npz")
+    norms = {k: torch.tensor(v) for k, v in C.CONTEXT_NORMS.items()}
+    f_nm, f_em, f_ctx, shift, rot = MU.ifm_prepare_gen_fragment_context(
+        fixed_fragment_x=g["frag_x"], reference_context=g["ref_context"], context_norms=norms, n_nodes=g["n_nodes"],
+        max_n_nodes=25, min_n_nodes=21, device=torch.device("cpu"))
+    assert torch.equal(f_nm, g["frag_node_mask"]) and float(f_em.sum()) == float(g["frag_edge_mask_sum"])
+    assert torch.allclose(shift, g["shift"], rtol=1e-6, atol=1e-6)
+    assert torch.allclose(f_ctx, g["frag_context"], rtol=1e-4, atol=1e-4)
+    # eigenvectors are defined up to sign: compare the action of the inverse transform up to that freedom
+    assert torch.allclose(rot.abs(), g["rotation"].abs(), atol=1e-4)
+    back = MU.inverse_coord_transform(coord=g["xg"], shift=g["shift"], rotation=g["rotation"])
+    assert torch.allclose(back, g["xg_back"], rtol=1e-6, atol=1e-6)
+    fh = MU.one_hot_classes(g["frag_z"].tolist()).float()
+    zk, fm = MU.ifm_prepare_fragments_for_merge(fixed_fragment_x=g["frag_x"], fixed_fragment_h=fh,
+                                                gen_fragments_x=g["xg_back"], gen_fragments_h=g["hg"],
+                                                device=torch.device("cpu"), max_n_nodes=25)
+    assert torch.equal(zk, g["z_known"]) and torch.equal(fm, g["fixed_mask"])
+    ms = MU.shift_moi_to_com_batch(torch.eye(3).unsqueeze(0).repeat(3, 1, 1) * 50.0, g["shift"],
+                                   torch.tensor([13.0, 15.0, 17.0]))
+    assert torch.allclose(ms, g["moi_shift"], rtol=1e-6, atol=1e-5)
+    with pytest.raises(ValueError, match="fewer atoms than minimum"):
+        MU.ifm_prepare_gen_fragment_context(g["frag_x"], g["ref_context"], norms, g["n_nodes"], 25, 8, torch.device("cpu"))

@@ -228,6 +228,29 @@ def main():
         err = type(e).__name__
     save("merge_level_gt_T.npz", error=np.array(err))
 
+    # 6b. inertial-fragment-matching front end: pure-tensor helpers run for real
+    ref_xyz, _ = parse_molblock_heavy_atoms(open("/root/reference/assets/demo_files/yibfeu.mol").read())
+    ref_ctx, _ = mu.get_context_shape(ref_xyz - ref_xyz.mean(0))
+    fx, fzs = parse_molblock_heavy_atoms(open("/root/reference/assets/demo_files/frag_yibfeu.mol").read())
+    fx = fx - ref_xyz.mean(0)                   # fragment in the reference's centred frame
+    n_nodes = torch.tensor([[21], [23], [25]])
+    f_nm, f_em, f_ctx, shift, rot = mu.ifm_prepare_gen_fragment_context(
+        fixed_fragment_x=fx, reference_context=ref_ctx, context_norms=norms, n_nodes=n_nodes,
+        max_n_nodes=25, min_n_nodes=21, device=torch.device("cpu"))
+    torch.manual_seed(61)
+    xg = torch.randn(3, 25 - fx.size(0), 3) * f_nm
+    hg = torch.nn.functional.one_hot(torch.randint(0, 7, (3, 25 - fx.size(0))), 8).float() * f_nm
+    xg_back = mu.inverse_coord_transform(coord=xg, shift=shift, rotation=rot)
+    fh = torch.zeros(fx.size(0), 8)
+    for i, zz in enumerate(fzs):
+        fh[i, cls[zz]] = 1
+    zk2, fm2 = mu.ifm_prepare_fragments_for_merge(fixed_fragment_x=fx, fixed_fragment_h=fh, gen_fragments_x=xg_back,
+                                                  gen_fragments_h=hg, device=torch.device("cpu"), max_n_nodes=25)
+    moi_shift = mu.shift_moi_to_com_batch(torch.eye(3).unsqueeze(0).repeat(3, 1, 1) * 50.0, shift, torch.tensor([13.0, 15.0, 17.0]))
+    save("ifm_front_end.npz", ref_context=ref_ctx, frag_x=fx, frag_z=torch.tensor(fzs), n_nodes=n_nodes,
+         frag_node_mask=f_nm, frag_edge_mask_sum=f_em.sum(), frag_context=f_ctx, shift=shift, rotation=rot,
+         xg=xg, hg=hg, xg_back=xg_back, z_known=zk2, fixed_mask=fm2, moi_shift=moi_shift)
+
     # 7. AdjMatSeer (a15), synthetic weights seed 4321
     gsd = W.synth_adj_mat_seer_state_dict(4321)
     gcn = ams.AdjMatSeer(dimension=42, n_hidden=2048, embedding_dim=64, num_embeddings=36, num_bond_types=5).eval()
