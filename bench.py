@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-phi-calls", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16 = opt-in reduced-precision MFMA operands (configs[4]); the default bench line is fp32")
     return ap.parse_args()
 
 
@@ -170,7 +172,7 @@ def main():
     sd = W.synth_edm_state_dict(1234)
     gsd = W.synth_adj_mat_seer_state_dict(4321)
     gen = MLConformerGenerator(diffusion_steps=args.diffusion_steps, device=dev, edm_weights=sd,
-                               adj_mat_seer_weights=gsd)
+                               adj_mat_seer_weights=gsd, compute_dtype=args.dtype)
     ctx = torch.tensor(DUMMY_CONTEXT)
     B = args.n_samples
     torch.manual_seed(7)                       # molecule sizes: CPU RNG, same on every rank
@@ -228,6 +230,7 @@ def main():
         edge_s = time_edge_kernel(gen, plan, dev)
         fl = edge_flops_per_launch(plan.n_real_edges)
         achieved = fl / edge_s / 1e12
+        peak_tf = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else 2500.0      # dense bf16 MFMA peak
         agg_s, agg_b = time_aggregate_kernel(plan, dev)
         finite = bool(torch.isfinite(last["x"]).all())
         # HBM bytes per launch of the dominant kernel come from the separate rocprofv3 --pmc passes
@@ -236,7 +239,7 @@ def main():
         try:
             pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
             key = f"configs[1]: n_samples={B}, n={args.n_atoms}"
-            if args.variance == 0 and key in pmc:
+            if args.variance == 0 and key in pmc and args.dtype == "f32":
                 traffic = pmc[key]["traffic_bytes_corrected"]
         except Exception:  # noqa: BLE001
             pass
@@ -244,7 +247,7 @@ def main():
             "metric": "valid molecules/sec @100 diffusion steps",
             "value": value, "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"configs[1]: n_samples={B}/GPU, {args.n_atoms}"
                                    f"{'+-' + str(args.variance) if args.variance else ''} heavy atoms, "
                                    f"diffusion_steps={args.diffusion_steps}, fp32 HIP EGNN + GCN",
@@ -258,8 +261,8 @@ def main():
             "egnn_step_ms_per_batch": egnn_step_ms,
             "outputs_finite": finite,
             "roofline": {"kernel": "k_edge (fused edge MLP: layer-1 finish + 420x420 MFMA + gate + per-node sum)",
-                         "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "bound": "mfma", "achieved": achieved, "peak": peak_tf, "unit": "TFLOP/s",
+                         "frac": achieved / peak_tf, "traffic": traffic,
                          "avg_launch_us": edge_s * 1e6, "flops_per_launch": fl},
             "aggregate_roofline": {"kernel": "k_aggregate (stand-alone gate*mask*segment-sum probe)", "bound": "hbm",
                                    "achieved": agg_b / agg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",

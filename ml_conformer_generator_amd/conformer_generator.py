@@ -45,7 +45,8 @@ class MLConformerGenerator(torch.nn.Module):
                  min_n_nodes: int = MIN_N_NODES, max_n_nodes: int = MAX_N_NODES,
                  context_norms: dict = CONTEXT_NORMS, atom_decoder: dict = ATOM_DECODER,
                  edm_weights: Union[str, dict] = "./edm_moi_chembl_15_39.pt",
-                 adj_mat_seer_weights: Union[str, dict] = "./adj_mat_seer_chembl_15_39.pt"):
+                 adj_mat_seer_weights: Union[str, dict] = "./adj_mat_seer_chembl_15_39.pt",
+                 compute_dtype: str = "f32"):
         super().__init__()
         _lib.lib()       # fail loudly if the HIP library is not built
         device = torch.device("cuda:0" if device is None else device)
@@ -66,6 +67,7 @@ class MLConformerGenerator(torch.nn.Module):
         adj_mat_seer = AdjMatSeer(dimension=dimension, n_hidden=2048, embedding_dim=64, num_embeddings=36,
                                   num_bond_types=num_bond_types, device=device)
         generative_model.load_state_dict(_load_state_dict(edm_weights, device))
+        net_dynamics.set_precision(compute_dtype)      # "bf16": opt-in reduced-precision MFMA operands
         adj_mat_seer.load_state_dict(_load_state_dict(adj_mat_seer_weights, device))
         # re-wire the schedule to the requested number of steps (conformer_generator.py:105-113)
         generative_model.gamma = PredefinedNoiseSchedule(timesteps=diffusion_steps, precision=NOISE_PRECISION)

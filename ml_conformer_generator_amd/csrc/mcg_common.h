@@ -22,6 +22,16 @@
 extern "C" void mcg_set_error(const char* fmt, ...);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// host: fp32 -> bf16 bits, round to nearest even (matches v_cvt_pk_bf16_f32)
+static inline uint16_t mcg_f32_to_bf16_bits(float f) {
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
 
 // ---------------------------------------------------------------------------------------
 // Packed GEMM operand ("B-pack").  A weight W[n_out][k_in] (nn.Linear layout) of a layer
@@ -58,6 +68,16 @@ __device__ __forceinline__ float mcg_silu(float x) { return x * mcg_sigmoid(x); 
 
 __device__ __forceinline__ f32x4 mcg_mfma(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 mcg_mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8 mcg_pack_bf16(const f32x4& lo, const f32x4& hi) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { r[j] = (__bf16)lo[j]; r[4 + j] = (__bf16)hi[j]; }
+    return r;
 }
 
 // sum over the 16 lanes that share (lane >> 4): xor-butterfly inside a 16-lane row

@@ -458,6 +458,102 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
 #endif
 }
 
+// ---- v2/bf16: same structure, operands rounded to bf16 (fp32 accumulate, fp32 epilogue) -------------
+// v_mfma_f32_16x16x32_bf16: one k-block of 32 per MFMA, K padded 420 -> 448 with zero weights (the
+// activation reads past column 420 land in finite padding / neighbouring data that the zeros cancel).
+// One LDS group = one k-block = 27 column tiles x 64 lanes x 8 bf16 = 27 KiB: the staging code and the
+// barrier protocol are those of the fp32 kernel, with 14 groups instead of 27.
+constexpr int KB16 = (H + 31) / 32;                // 14
+constexpr int PD16 = 4;                            // B-fragment ring depth (4 VGPRs per fragment)
+
+template <bool EQUIV>
+__global__ __launch_bounds__(256, 2) void k_edge_lds_bf16(EdgeArgs p) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * GROUP_LDS_FLOATS];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int wave_raw = blockIdx.x * 4 + wid;
+    const bool live = wave_raw < p.n_waves;
+    const int wave = live ? wave_raw : p.n_waves - 1;
+    RowInfo<1> R;
+    edge_decode<1, EQUIV>(p, wave, live, c, R);
+
+    f32x4 acc[1][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* pa = p.pab + (size_t)R.ni[0] * (2 * HP) + 8 * g;
+    const float* pb = p.pab + (size_t)R.nj[0] * (2 * HP) + HP + 8 * g;
+    const float* wdp = p.wd + 8 * g;
+    const float* w0p = p.wd0 + 8 * g;
+
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.Bp), 0, KB16 * GROUP_FLOATS * 4, 0x00020000);
+    auto stage = [&](int q, int buf) {
+        float* dst = lds + buf * GROUP_LDS_FLOATS;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int piece = wid + 4 * i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(brsrc, (__attribute__((address_space(3))) void*)(dst + piece * 256), 16,
+                                                     lane * 16, (q * GROUP_FLOATS + piece * 256) * 4, 0, 0);
+        }
+    };
+    auto agen = [&](const f32x4 (&v)[8]) -> bf16x8 {     // v = {pa0,pa1,pb0,pb1,wd0,wd1,w00,w01}
+        f32x4 lo, hi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lo[j] = mcg_silu(fmaf(v[6][j], R.d02[0], fmaf(v[4][j], R.d2[0], v[0][j] + v[2][j])));
+            hi[j] = mcg_silu(fmaf(v[7][j], R.d02[0], fmaf(v[5][j], R.d2[0], v[1][j] + v[3][j])));
+        }
+        return mcg_pack_bf16(lo, hi);
+    };
+    auto load_a = [&](int kb, f32x4 (&v)[8]) {
+        v[0] = *reinterpret_cast<const f32x4*>(pa + 32 * kb);  v[1] = *reinterpret_cast<const f32x4*>(pa + 32 * kb + 4);
+        v[2] = *reinterpret_cast<const f32x4*>(pb + 32 * kb);  v[3] = *reinterpret_cast<const f32x4*>(pb + 32 * kb + 4);
+        v[4] = *reinterpret_cast<const f32x4*>(wdp + 32 * kb); v[5] = *reinterpret_cast<const f32x4*>(wdp + 32 * kb + 4);
+        v[6] = *reinterpret_cast<const f32x4*>(w0p + 32 * kb); v[7] = *reinterpret_cast<const f32x4*>(w0p + 32 * kb + 4);
+    };
+
+    stage(0, 0);
+    bf16x8 a8;
+    {
+        f32x4 v[8];
+        load_a(0, v);
+        a8 = agen(v);
+    }
+#pragma unroll 1
+    for (int kb = 0; kb < KB16; ++kb) {
+        const int buf = kb & 1;
+        asm volatile("s_barrier" ::: "memory");                    // (A) buffer buf^1 is free again
+        f32x4 v[8];
+        const int kn = kb + 1 < KB16 ? kb + 1 : kb;                // (last block: harmless reload)
+        load_a(kn, v);
+        stage(kn, buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(15)" ::: "memory");          // my 7 pieces of block kb have landed
+        asm volatile("s_barrier" ::: "memory");                    // (B)
+        const bf16x8* lb = reinterpret_cast<const bf16x8*>(lds + buf * GROUP_LDS_FLOATS) + lane;
+        bf16x8 bq[PD16];
+#pragma unroll
+        for (int i = 0; i < PD16; ++i) bq[i] = lb[i * 64];
+        bf16x8 a8n;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const bf16x8 b = bq[nt % PD16];
+            if (nt + PD16 < NT) bq[nt % PD16] = lb[(nt + PD16) * 64];
+            acc[0][nt] = mcg_mfma_bf16(a8, b, acc[0][nt]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (nt == NT / 2) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(v[i]));
+                a8n = agen(v);
+            }
+        }
+        a8 = a8n;
+    }
+    edge_epilogue<1, EQUIV>(p, wave, live, lane, acc, R);
+}
+
 // agg[v] = (sum of the per-wave partials that cover node v) / 100   (egnn.py:429-435)
 __global__ __launch_bounds__(128) void k_combine_agg(const float* __restrict__ P, const int* __restrict__ node_mol,
                                                       const int* __restrict__ node_off, const int* __restrict__ row_off,
@@ -572,6 +668,11 @@ int upload(const std::vector<float>& v, float** d) {
     MCG_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
     return MCG_OK;
 }
+int upload16(const std::vector<uint16_t>& v, uint16_t** d) {
+    MCG_HIP(hipMalloc((void**)d, v.size() * sizeof(uint16_t) + 64));
+    MCG_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return MCG_OK;
+}
 int upload_i(const std::vector<int>& v, int** d) {
     MCG_HIP(hipMalloc((void**)d, (v.size() ? v.size() : 1) * sizeof(int)));
     if (v.size()) MCG_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -582,15 +683,18 @@ struct EdgeLayer {      // second layer + head of an edge MLP, and its factorise
     float *pab_Bp = nullptr, *pab_bias = nullptr, *wd = nullptr, *wd0 = nullptr;
     float *w2_Bp = nullptr, *b2 = nullptr, *wv = nullptr;
     float bv = 0.f;
+    uint16_t *pab_Bp16 = nullptr, *w2_Bp16 = nullptr;     // bf16 operand packs
 };
 struct NodeLayer {
     float *w3_Bp = nullptr, *b3 = nullptr, *w4_Bp = nullptr, *b4 = nullptr;
+    uint16_t *w3_Bp16 = nullptr, *w4_Bp16 = nullptr;
 };
 
 }  // namespace
 
 struct mcg_egnn {
     int n_blocks = 0;
+    bool bf16 = false;          // MFMA operands rounded to bf16 (opt-in, mcg_egnn_set_precision)
     float *emb_wT = nullptr, *emb_b = nullptr, *out_w = nullptr, *out_b = nullptr;
     std::vector<EdgeLayer> gcl_edge;   // 2 per block
     std::vector<NodeLayer> gcl_node;   // 2 per block
@@ -632,7 +736,7 @@ int build_edge_layer(mcg_egnn* m, EdgeLayer& L, const float* w1 /*[420][842]*/, 
     for (int n = 0; n < H; ++n) v[n] = b1[n];
     if (int e = upload(v, &L.pab_bias)) return e;
     m->allocs.push_back(L.pab_bias);
-    v.assign(HP, 0.f);
+    v.assign(HP + 32, 0.f);     // (+32: the bf16 kernel reads k up to 447)
     for (int n = 0; n < H; ++n) v[n] = w1[(size_t)n * (2 * H + 2) + 2 * H];       // current d2 column (egnn.py:199)
     if (int e = upload(v, &L.wd)) return e;
     m->allocs.push_back(L.wd);
@@ -643,6 +747,20 @@ int build_edge_layer(mcg_egnn* m, EdgeLayer& L, const float* w1 /*[420][842]*/, 
     pack_B(buf, H, NT, [&](int n, int k) -> float { return n < H ? w2[(size_t)n * H + k] : 0.f; }, GROUP_LDS_FLOATS);
     if (int e = upload(buf, &L.w2_Bp)) return e;
     m->allocs.push_back(L.w2_Bp);
+    {   // bf16 operand packs of the same weights
+        std::vector<uint16_t> b16;
+        mcg_pack_b16(b16, H, 2 * NT, [&](int n, int k) -> float {
+            if (n < HP) return n < H ? w1[(size_t)n * (2 * H + 2) + k] : 0.f;
+            const int nn = n - HP;
+            return nn < H ? w1[(size_t)nn * (2 * H + 2) + H + k] : 0.f;
+        });
+        if (int e = upload16(b16, &L.pab_Bp16)) return e;
+        m->allocs.push_back(L.pab_Bp16);
+        b16.clear();
+        mcg_pack_b16(b16, H, NT, [&](int n, int k) -> float { return n < H ? w2[(size_t)n * H + k] : 0.f; });
+        if (int e = upload16(b16, &L.w2_Bp16)) return e;
+        m->allocs.push_back(L.w2_Bp16);
+    }
     v.assign(HP, 0.f);
     for (int n = 0; n < H; ++n) v[n] = b2[n];
     if (int e = upload(v, &L.b2)) return e;
@@ -671,6 +789,17 @@ int build_node_layer(mcg_egnn* m, NodeLayer& L, const float* w3 /*[420][840]*/, 
     mcg_pack_b4(buf, H, NT, [&](int n, int k) -> float { return n < H ? w4[(size_t)n * H + k] : 0.f; });
     if (int e = upload(buf, &L.w4_Bp)) return e;
     m->allocs.push_back(L.w4_Bp);
+    {
+        std::vector<uint16_t> b16;
+        mcg_pack_b16(b16, H, NT, [&](int n, int k) -> float { return n < H ? w3[(size_t)n * (2 * H) + k] : 0.f; });
+        mcg_pack_b16(b16, H, NT, [&](int n, int k) -> float { return n < H ? w3[(size_t)n * (2 * H) + H + k] : 0.f; });
+        if (int e = upload16(b16, &L.w3_Bp16)) return e;
+        m->allocs.push_back(L.w3_Bp16);
+        b16.clear();
+        mcg_pack_b16(b16, H, NT, [&](int n, int k) -> float { return n < H ? w4[(size_t)n * H + k] : 0.f; });
+        if (int e = upload16(b16, &L.w4_Bp16)) return e;
+        m->allocs.push_back(L.w4_Bp16);
+    }
     for (int n = 0; n < H; ++n) v[n] = b4[n];
     if (int e = upload(v, &L.b4)) return e;
     m->allocs.push_back(L.b4);
@@ -695,13 +824,21 @@ void launch_edge(bool equiv, const EdgeArgs& a, int n_waves, hipStream_t s) {
     else hipLaunchKernelGGL((k_edge<MT, false>), dim3(n_waves), dim3(64), 0, s, a);
 }
 
-int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipStream_t s) {
+int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipStream_t s, bool bf16 = false) {
     if (pl->n_waves == 0) return MCG_OK;
     EdgeArgs a;
     a.pab = pl->pab; a.x = pl->x; a.x0 = pl->x0; a.wd = L.wd; a.wd0 = L.wd0; a.Bp = L.w2_Bp; a.b2 = L.b2;
     a.wv = L.wv; a.bv = L.bv; a.n_nodes = pl->n_nodes; a.node_off = pl->node_off; a.row_off = pl->row_off;
     a.B = pl->B; a.tile_mol = pl->tile_mol; a.wave_nf = pl->wave_nf; a.wave_poff = pl->wave_poff;
     a.n_rows = pl->n_rows; a.n_mtiles = pl->n_mtiles; a.n_waves = pl->n_waves; a.P = P;
+    if (bf16 && pl->MT == 1) {
+        a.Bp = reinterpret_cast<const float*>(L.w2_Bp16);
+        const int wgs = (pl->n_waves + 3) / 4;
+        if (equiv) hipLaunchKernelGGL((k_edge_lds_bf16<true>), dim3(wgs), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_edge_lds_bf16<false>), dim3(wgs), dim3(256), 0, s, a);
+        MCG_HIP(hipGetLastError());
+        return MCG_OK;
+    }
     switch (pl->MT) {
         case 1: launch_edge<1>(equiv, a, pl->n_waves, s); break;
         case 2: launch_edge<2>(equiv, a, pl->n_waves, s); break;
@@ -712,11 +849,13 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
 }
 
 int gemm(const float* A1, int lda1, int K1, const float* A2, int lda2, int K2, const float* Bp, const float* bias,
-         const float* resid, int ldr, float* C, int ldc, int M, int n_tiles, int n_store, int act, hipStream_t s) {
+         const float* resid, int ldr, float* C, int ldc, int M, int n_tiles, int n_store, int act, hipStream_t s,
+         const uint16_t* Bp16 = nullptr) {
     McgGemmArgs g;
     g.A1 = A1; g.lda1 = lda1; g.K1 = K1; g.A2 = A2; g.lda2 = lda2; g.K2 = K2; g.Bp = Bp; g.bias = bias;
     g.resid = resid; g.ldr = ldr; g.C = C; g.ldc = ldc; g.M = M; g.n_tiles = n_tiles; g.n_store = n_store; g.act = act;
-    MCG_HIP(mcg_gemm_launch(g, s));
+    if (Bp16) g.Bp = reinterpret_cast<const float*>(Bp16);
+    MCG_HIP(mcg_gemm_launch(g, s, Bp16 != nullptr));
     return MCG_OK;
 }
 
@@ -725,17 +864,18 @@ int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s) {
     const EdgeLayer& E = m->gcl_edge[layer];
     const NodeLayer& Nl = m->gcl_node[layer];
     const int M = pl->M;
+    const bool lp = m->bf16;
     if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
-                     MCG_ACT_NONE, s)) return e;
-    if (int e = run_edge(pl, E, false, pl->P, s)) return e;
+                     MCG_ACT_NONE, s, lp ? E.pab_Bp16 : nullptr)) return e;
+    if (int e = run_edge(pl, E, false, pl->P, s, lp)) return e;
     hipLaunchKernelGGL(k_combine_agg, dim3(M), dim3(128), 0, s, pl->P, pl->node_mol, pl->node_off, pl->row_off,
                        pl->n_nodes, pl->wave_nf, pl->wave_poff, 16 * pl->MT, pl->agg);
     MCG_HIP(hipGetLastError());
     // node_mlp: h + W4 silu(W3 [h | agg] + b3) + b4   (egnn.py:30-34,66-67)
-    if (int e = gemm(pl->h, HP, H, pl->agg, HP, H, Nl.w3_Bp, Nl.b3, nullptr, 0, pl->t1, HP, M, NT, HP, MCG_ACT_SILU, s))
-        return e;
-    if (int e = gemm(pl->t1, HP, H, nullptr, 0, 0, Nl.w4_Bp, Nl.b4, pl->h, HP, pl->h2, HP, M, NT, HP, MCG_ACT_NONE, s))
-        return e;
+    if (int e = gemm(pl->h, HP, H, pl->agg, HP, H, Nl.w3_Bp, Nl.b3, nullptr, 0, pl->t1, HP, M, NT, HP, MCG_ACT_SILU, s,
+                     lp ? Nl.w3_Bp16 : nullptr)) return e;
+    if (int e = gemm(pl->t1, HP, H, nullptr, 0, 0, Nl.w4_Bp, Nl.b4, pl->h, HP, pl->h2, HP, M, NT, HP, MCG_ACT_NONE, s,
+                     lp ? Nl.w4_Bp16 : nullptr)) return e;
     std::swap(pl->h, pl->h2);
     return MCG_OK;
 }
@@ -744,8 +884,8 @@ int run_equiv(const mcg_egnn* m, mcg_plan* pl, int block, hipStream_t s) {
     const EdgeLayer& E = m->equiv[block];
     const int M = pl->M;
     if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
-                     MCG_ACT_NONE, s)) return e;
-    if (int e = run_edge(pl, E, true, pl->Px, s)) return e;
+                     MCG_ACT_NONE, s, m->bf16 ? E.pab_Bp16 : nullptr)) return e;
+    if (int e = run_edge(pl, E, true, pl->Px, s, m->bf16)) return e;
     const int threads = M * 4;
     hipLaunchKernelGGL(k_coord_update, dim3((threads + 255) / 256), dim3(256), 0, s, pl->Px, pl->node_mol, pl->node_off,
                        pl->row_off, pl->n_nodes, pl->wave_nf, pl->wave_poff, 16 * pl->MT, M, pl->x);
@@ -810,6 +950,14 @@ int mcg_egnn_create(const float* const* tensors, int n_tensors, int hidden, int 
         idx += 5;
     }
     *out = m;
+    return MCG_OK;
+}
+
+// bf16 = 1: MFMA operands (activations and weights) rounded to bf16, fp32 accumulate and epilogue
+// (BASELINE.json configs[4]); bf16 = 0 (default): exact fp32 MFMA.
+int mcg_egnn_set_precision(mcg_egnn* m, int bf16) {
+    if (!m) return MCG_ERR_ARG;
+    m->bf16 = bf16 != 0;
     return MCG_OK;
 }
 
@@ -883,8 +1031,9 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
                                        (void*)p->wave_nf, (void*)p->wave_poff, (void*)p->node_mol});
     const size_t M1 = (size_t)(p->M > 0 ? p->M : 1);
     struct { float** ptr; size_t n; } bufs[] = {
-        {&p->x, M1 * 4}, {&p->x0, M1 * 4}, {&p->h, M1 * HP}, {&p->h2, M1 * HP}, {&p->pab, M1 * 2 * HP},
-        {&p->agg, M1 * HP}, {&p->t1, M1 * HP}, {&p->P, (size_t)(p->n_pslots + 1) * HP}, {&p->Px, (size_t)(p->n_pslots + 1) * 4}};
+        // (+64 floats: the bf16 kernels read activation rows up to k = 447, i.e. 16 floats past the last row)
+        {&p->x, M1 * 4}, {&p->x0, M1 * 4}, {&p->h, M1 * HP + 64}, {&p->h2, M1 * HP + 64}, {&p->pab, M1 * 2 * HP + 64},
+        {&p->agg, M1 * HP + 64}, {&p->t1, M1 * HP + 64}, {&p->P, (size_t)(p->n_pslots + 1) * HP}, {&p->Px, (size_t)(p->n_pslots + 1) * 4}};
     for (auto& b : bufs) {
         MCG_HIP(hipMalloc((void**)b.ptr, b.n * sizeof(float)));
         MCG_HIP(hipMemset(*b.ptr, 0, b.n * sizeof(float)));
@@ -983,7 +1132,7 @@ int mcg_bench_edge(const mcg_egnn* m, mcg_plan* pl, int layer, int equiv, int it
     if (!m || !pl || iters < 1 || layer < 0 || layer >= (equiv ? m->n_blocks : 2 * m->n_blocks)) return MCG_ERR_ARG;
     for (int i = 0; i < iters; ++i)
         if (int e = run_edge(pl, equiv ? m->equiv[layer] : m->gcl_edge[layer], equiv != 0, equiv ? pl->Px : pl->P,
-                             (hipStream_t)stream)) return e;
+                             (hipStream_t)stream, m->bf16)) return e;
     return MCG_OK;
 }
 

@@ -15,6 +15,7 @@
 #pragma once
 #include "mcg_common.h"
 
+#include <cstdlib>
 #include <vector>
 
 enum { MCG_ACT_NONE = 0, MCG_ACT_SILU = 1, MCG_ACT_RELU = 2 };
@@ -49,6 +50,124 @@ static void mcg_pack_b4(std::vector<float>& dst, int K, int n_tiles, F value /* 
         for (int nt = 0; nt < n_tiles; ++nt)
             for (int l = 0; l < 64; ++l)
                 t[((size_t)st * n_tiles + nt) * 64 + l] = value(nt * 16 + (l & 15), 16 * groups + 4 * st + (l >> 4));
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16-operand variant (fp32 accumulate, fp32 in/out): v_mfma_f32_16x16x32_bf16.  K is consumed in
+// blocks of 32 (K padded up with ZERO weights; the activation rows are read past K into finite
+// padding/neighbouring data that the zero weights cancel).  "B-pack16" layout per K segment:
+//   Bp16[((kb * n_tiles + nt) * 64 + lane) * 8 + j] = bf16( W[16 nt + (lane&15)][32 kb + 8 (lane>>4) + j] )
+// A rows are loaded as fp32 (two 16-byte loads per k-block) and rounded to bf16 in registers.
+__host__ __device__ static inline int mcg_kblocks16(int K) { return (K + 31) / 32; }
+__host__ __device__ static inline size_t mcg_pack16_elems(int K, int n_tiles) { return (size_t)mcg_kblocks16(K) * n_tiles * 64 * 8; }
+
+template <class F>
+static void mcg_pack_b16(std::vector<uint16_t>& dst, int K, int n_tiles, F value /* (n, k) -> W[n][k] or 0 */) {
+    const size_t base = dst.size();
+    dst.resize(base + mcg_pack16_elems(K, n_tiles), 0);
+    uint16_t* d = dst.data() + base;
+    for (int kb = 0; kb < mcg_kblocks16(K); ++kb)
+        for (int nt = 0; nt < n_tiles; ++nt)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 32 * kb + 8 * (l >> 4) + j;
+                    d[(((size_t)kb * n_tiles + nt) * 64 + l) * 8 + j] = k < K ? mcg_f32_to_bf16_bits(value(nt * 16 + (l & 15), k)) : 0;
+                }
+}
+
+template <int RN>
+__global__ __launch_bounds__(256) void mcg_gemm_bf16_kernel(McgGemmArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int wave_cols = (p.n_tiles + RN - 1) / RN;
+    const int wlin = blockIdx.x * 4 + wid;
+    if (wlin >= ((p.M + 31) / 32) * wave_cols) return;
+    const int row0 = (wlin / wave_cols) * 32;
+    const int nt0 = (wlin % wave_cols) * RN;
+    int rA[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int r = row0 + 16 * m + c;
+        rA[m] = r < p.M ? r : p.M - 1;
+    }
+    bool nvalid[RN];
+    int ncl[RN];
+#pragma unroll
+    for (int n = 0; n < RN; ++n) {
+        nvalid[n] = nt0 + n < p.n_tiles;
+        ncl[n] = nvalid[n] ? n : 0;
+    }
+    f32x4 acc[2][RN];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < RN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const bf16x8* bseg = reinterpret_cast<const bf16x8*>(p.Bp);
+#pragma unroll 1
+    for (int seg = 0; seg < 2; ++seg) {
+        const float* A = seg == 0 ? p.A1 : p.A2;
+        const int K = seg == 0 ? p.K1 : p.K2;
+        const int lda = seg == 0 ? p.lda1 : p.lda2;
+        if (K == 0) continue;
+        const float* a0 = A + (size_t)rA[0] * lda + 8 * g;
+        const float* a1 = A + (size_t)rA[1] * lda + 8 * g;
+        const int blocks = mcg_kblocks16(K);
+        const size_t bstride = (size_t)p.n_tiles * 64;        // bf16x8 elements per k-block
+        const bf16x8* bq = bseg + (size_t)nt0 * 64 + lane;
+        // 3-deep register ring, same discipline as the fp32 kernel (pinned order, unconditional loads)
+        f32x4 Ar[3][2][2];
+        bf16x8 Br[3][RN];
+        auto load_block = [&](int slot, int kb) {
+            kb = kb < blocks ? kb : blocks - 1;
+            Ar[slot][0][0] = *reinterpret_cast<const f32x4*>(a0 + 32 * kb);
+            Ar[slot][0][1] = *reinterpret_cast<const f32x4*>(a0 + 32 * kb + 4);
+            Ar[slot][1][0] = *reinterpret_cast<const f32x4*>(a1 + 32 * kb);
+            Ar[slot][1][1] = *reinterpret_cast<const f32x4*>(a1 + 32 * kb + 4);
+#pragma unroll
+            for (int n = 0; n < RN; ++n) Br[slot][n] = bq[(size_t)kb * bstride + ncl[n] * 64];
+        };
+        auto compute = [&](int slot) {
+            const bf16x8 A0 = mcg_pack_bf16(Ar[slot][0][0], Ar[slot][0][1]);
+            const bf16x8 A1 = mcg_pack_bf16(Ar[slot][1][0], Ar[slot][1][1]);
+#pragma unroll
+            for (int n = 0; n < RN; ++n) {
+                acc[0][n] = mcg_mfma_bf16(A0, Br[slot][n], acc[0][n]);
+                acc[1][n] = mcg_mfma_bf16(A1, Br[slot][n], acc[1][n]);
+            }
+        };
+        load_block(0, 0); load_block(1, 1); load_block(2, 2);
+        int kb = 0;
+#pragma unroll 1
+        for (; kb + 3 <= blocks; kb += 3) {
+            compute(0); __builtin_amdgcn_sched_barrier(0); load_block(0, kb + 3); __builtin_amdgcn_sched_barrier(0);
+            compute(1); __builtin_amdgcn_sched_barrier(0); load_block(1, kb + 4); __builtin_amdgcn_sched_barrier(0);
+            compute(2); __builtin_amdgcn_sched_barrier(0); load_block(2, kb + 5); __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kb < blocks) compute(0);
+        if (kb + 1 < blocks) compute(1);
+        bseg += (size_t)blocks * bstride;
+    }
+#pragma unroll
+    for (int n = 0; n < RN; ++n) {
+        if (!nvalid[n]) continue;
+        const int col = (nt0 + n) * 16 + c;
+        if (col >= p.n_store) continue;
+        const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int orow = row0 + 16 * m + 4 * g + r;
+                if (orow >= p.M) continue;
+                float v = acc[m][n][r] + bias;
+                if (p.act == MCG_ACT_SILU) v = mcg_silu(v);
+                else if (p.act == MCG_ACT_RELU) v = fmaxf(v, 0.f);
+                if (p.resid) v += p.resid[(size_t)orow * p.ldr + col];
+                p.C[(size_t)orow * p.ldc + col] = v;
+            }
+    }
 }
 
 template <int RN>
@@ -174,7 +293,7 @@ __global__ __launch_bounds__(256) void mcg_gemm_kernel(McgGemmArgs p) {
     }
 }
 
-static inline hipError_t mcg_gemm_launch(const McgGemmArgs& a, hipStream_t s) {
+static inline hipError_t mcg_gemm_launch(const McgGemmArgs& a, hipStream_t s, bool bf16 = false) {
     if (a.M <= 0) return hipSuccess;
     const int rowblocks = (a.M + 31) / 32;
     // wave tile width RN in {1,2,3}: minimise (rounds of 256 four-wave workgroups) x (work per wave ~ RN);
@@ -187,8 +306,15 @@ static inline hipError_t mcg_gemm_launch(const McgGemmArgs& a, hipStream_t s) {
         const long cost = ((wgs + 255) / 256) * cand;
         if (best < 0 || cost <= best) { best = cost; rn = cand; }
     }
+    if (const char* e = getenv("MCG_GEMM_RN")) { const int v = atoi(e); if (v >= 1 && v <= 3) rn = v; }
     const long waves = (long)rowblocks * ((a.n_tiles + rn - 1) / rn);
     dim3 grid((unsigned)((waves + 3) / 4));
+    if (bf16) {
+        if (rn == 3) hipLaunchKernelGGL(mcg_gemm_bf16_kernel<3>, grid, dim3(256), 0, s, a);
+        else if (rn == 2) hipLaunchKernelGGL(mcg_gemm_bf16_kernel<2>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(mcg_gemm_bf16_kernel<1>, grid, dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     if (rn == 3) hipLaunchKernelGGL(mcg_gemm_kernel<3>, grid, dim3(256), 0, s, a);
     else if (rn == 2) hipLaunchKernelGGL(mcg_gemm_kernel<2>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(mcg_gemm_kernel<1>, grid, dim3(256), 0, s, a);

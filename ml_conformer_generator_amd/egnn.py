@@ -78,6 +78,7 @@ class EGNNDynamics(torch.nn.Module):
         self.hidden_nf, self.n_blocks = hidden_nf, n_blocks
         self.device = torch.device(device)
         self._h = C.c_void_p()
+        self.compute_dtype = "f32"
         self._plans: Dict[tuple, BatchPlan] = {}
 
     # -- weights ------------------------------------------------------------------
@@ -107,6 +108,15 @@ class EGNNDynamics(torch.nn.Module):
         if not self._h:
             raise _lib.McgError("EGNNDynamics has no weights loaded")
         return self._h
+
+    def set_precision(self, compute_dtype: str = "f32") -> None:
+        """"f32" (default): exact fp32 MFMA.  "bf16": MFMA operands rounded to bf16, fp32 accumulate,
+        fp32 coordinates/aggregates/epilogues (BASELINE.json configs[4])."""
+        if compute_dtype not in ("f32", "bf16"):
+            raise ValueError("compute_dtype must be 'f32' or 'bf16'")
+        _lib.check(_lib.lib().mcg_egnn_set_precision(self.handle, 1 if compute_dtype == "bf16" else 0),
+                   "mcg_egnn_set_precision")
+        self.compute_dtype = compute_dtype
 
     # -- plans --------------------------------------------------------------------
     def plan(self, n_nodes: torch.Tensor, max_n_nodes: int, edge_mt: int = 0) -> BatchPlan:

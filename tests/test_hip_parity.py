@@ -368,3 +368,86 @@ def test_generator_fixed_fragment_modes(edm_sd, gcn_sd, ifm):
     with pytest.raises(IndexError):                                         # level > steps, as the reference
         gen.edm_tensors(g["ref_context"], n_samples=2, min_n_nodes=21, max_n_nodes=25, fixed_fragment=frag,
                         inertial_fragment_matching=True, ifm_diffusion_level=50)
+
+
+# ------------------------------------------------------------------------------- bf16 operand mode (configs[4])
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _egnn_dynamics_bf16_emulated(sd, t, xh, node_mask, edge_mask, context):
+    """fp32 torch emulation of what the bf16 mode computes: the reference network with the OPERANDS of
+    every hidden-size contraction rounded to bf16 (fp32 accumulate) and the first edge layer in its
+    factorised form - a yardstick that separates 'bf16 rounding' from 'kernel bug'."""
+    import torch.nn.functional as F
+    from oracle import egnn_oracle as EO
+    B, N, _ = xh.shape
+    row, col = EO.dense_edge_index(N, B)
+    nm = node_mask.reshape(B * N, 1)
+    em = edge_mask.reshape(B * N * N, 1)
+    flat = xh.reshape(B * N, -1) * nm
+    x0 = flat[:, :3].clone()
+    h = torch.cat([flat[:, 3:], t.reshape(B, 1).repeat(1, N).reshape(B * N, 1), context.reshape(B * N, -1)], 1)
+    p0 = "dynamics.egnn."
+    h = F.linear(h, sd[p0 + "embedding.weight"], sd[p0 + "embedding.bias"])
+    x = x0.clone()
+    d0, _ = EO.pair_geometry(x0, row, col)
+
+    def lin16(a, w, b=None):
+        return F.linear(_bf(a), _bf(w), b)
+
+    def edge_mlp(p, key, h, d2):
+        w1, b1 = sd[p + key + ".0.weight"], sd[p + key + ".0.bias"]
+        pa = lin16(h, w1[:, :420], b1)
+        pb = lin16(h, w1[:, 420:840])
+        pre = pa[row] + pb[col] + d2 * w1[:, 840] + d0 * w1[:, 841]
+        return F.silu(lin16(F.silu(pre), sd[p + key + ".2.weight"], sd[p + key + ".2.bias"]))
+
+    for k in range(9):
+        bp = f"{p0}e_block_{k}."
+        d2, unit = EO.pair_geometry(x, row, col)
+        for gname in ("gcl_0.", "gcl_1."):
+            p = bp + gname
+            m = edge_mlp(p, "edge_mlp", h, d2)
+            gate = torch.sigmoid(F.linear(m, sd[p + "att_mlp.0.weight"], sd[p + "att_mlp.0.bias"]))
+            agg = EO.segment_sum(m * gate * em, row, h.size(0))
+            hid = F.silu(lin16(torch.cat([h, agg], 1), sd[p + "node_mlp.0.weight"], sd[p + "node_mlp.0.bias"]))
+            h = (h + lin16(hid, sd[p + "node_mlp.2.weight"], sd[p + "node_mlp.2.bias"])) * nm
+        p = bp + "gcl_equiv."
+        m = edge_mlp(p, "coord_mlp", h, d2)
+        phi = F.linear(m, sd[p + "coord_mlp.4.weight"])
+        x = (x + EO.segment_sum(unit * phi * em, row, x.size(0))) * nm
+    h = F.linear(h, sd[p0 + "embedding_out.weight"], sd[p0 + "embedding_out.bias"]) * nm
+    vel = EO.masked_mean_removal(((x - x0) * nm).reshape(B, N, 3), node_mask.reshape(B, N, 1))
+    return torch.cat([vel, h[:, :8].reshape(B, N, -1)], dim=2)
+
+
+def test_bf16_mode_vs_emulation_and_fp32(edm_sd):
+    from ml_conformer_generator_amd.egnn import EGNNDynamics
+    from oracle import egnn_oracle as EO
+    from oracle import host_oracle as HO
+    d = EGNNDynamics(device=DEV)
+    d.load_reference_state_dict(edm_sd)
+    d.set_precision("bf16")
+    torch.manual_seed(11)
+    sizes = torch.tensor([19, 27, 15, 33])
+    N = 33
+    nm, em = HO.masks_from_sizes(sizes, N)
+    z = torch.randn(4, N, 11) * nm
+    ctx = torch.randn(4, 1, 3).repeat(1, N, 1) * nm
+    t = torch.full((4, 1), 0.4)
+    out = d(t.to(DEV), z.to(DEV), nm.to(DEV), em.to(DEV), ctx.to(DEV)).cpu()
+    emu = _egnn_dynamics_bf16_emulated(edm_sd, t, z, nm, em, ctx)
+    ref = EO.egnn_dynamics(edm_sd, t, z, nm, em, ctx)
+    sc = float(ref.abs().max())
+    e_emu = float((out - emu).abs().max()) / sc
+    e_ref = float((out - ref).abs().max()) / sc
+    e_floor = float((emu - ref).abs().max()) / sc            # what bf16 operand rounding itself costs
+    # stated bf16 tolerance: 3e-3 of max|out| vs the bf16-operand emulation (accumulation-order +
+    # rounding-boundary effects only), 3e-2 vs the fp32 reference
+    assert e_emu < 3e-3, (e_emu, e_ref, e_floor)
+    assert e_ref < 3e-2, (e_emu, e_ref, e_floor)
+    assert float((out * (1 - nm)).abs().max()) == 0.0
+    d.set_precision("f32")
+    out32 = d(t.to(DEV), z.to(DEV), nm.to(DEV), em.to(DEV), ctx.to(DEV)).cpu()
+    assert float((out32 - ref).abs().max()) / sc < 1e-5

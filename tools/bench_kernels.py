@@ -11,10 +11,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="c2")
 ap.add_argument("--mt", type=int, default=0)
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--dtype", default="f32")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 dyn = EGNNDynamics(device=dev)
 dyn.load_reference_state_dict(W.synth_edm_state_dict(1234))
+dyn.set_precision(a.dtype)
 if a.shape == "c2":
     sizes = torch.full((64,), 27, dtype=torch.int32); N = 27
 else:
@@ -34,5 +36,5 @@ ms_eq = timed(lambda: L.mcg_bench_edge(dyn.handle, plan.handle, 4, 1, 10, st), 5
 ms_phi = timed(lambda: dyn.run(plan, t, z, ctx, out), a.iters)
 E = plan.n_real_edges
 fl = 2.0 * E * (420 * 420 + 3 * 420)
-print(f"shape={a.shape} variant={os.environ.get('MCG_EDGE_KERNEL','1')} mt={plan.edge_mt} waves={plan.n_edge_waves} E={E} M={plan.n_real_nodes} "
+print(f"dtype={a.dtype} shape={a.shape} variant={os.environ.get('MCG_EDGE_KERNEL','1')} mt={plan.edge_mt} waves={plan.n_edge_waves} E={E} M={plan.n_real_nodes} "
       f"edge_gcl={ms_edge*1e3:.1f}us ({fl/ms_edge/1e9:.1f} TF/s) edge_equiv={ms_eq*1e3:.1f}us phi={ms_phi:.3f}ms")
