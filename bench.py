@@ -166,7 +166,7 @@ def main():
     from ml_conformer_generator_amd import MLConformerGenerator
     from ml_conformer_generator_amd import weights as W
     from ml_conformer_generator_amd.distributed import gather_results, rank_seed
-    from ml_conformer_generator_amd.handoff import prepare_adj_mat_seer_input_native
+    from ml_conformer_generator_amd.handoff import prepare_adj_mat_seer_input_hip
     from ml_conformer_generator_amd.synthetic import DUMMY_CONTEXT
 
     sd = W.synth_edm_state_dict(1234)
@@ -188,7 +188,7 @@ def main():
                                           max_n_nodes=args.n_atoms + args.variance)
         ev1.record()
         n_nodes = node_mask.sum(1).reshape(-1).to(torch.long)
-        el, dm, am = prepare_adj_mat_seer_input_native(x, h, n_nodes, 42)
+        el, dm, am = prepare_adj_mat_seer_input_hip(x, h, n_nodes, 42)
         bond = gen.adj_mat_seer.bond_orders(el, dm, am)
         res = {"x": x, "elements": el.to(torch.int8), "bond": bond, "n_nodes": n_nodes.to(torch.int32)}
         res = gather_results(res, B * world)

@@ -105,7 +105,13 @@ void mcg_gcn_destroy(mcg_gcn* g);
  * Either output may be NULL. */
 int mcg_gcn_forward(mcg_gcn* g, const int64_t* elements, const float* dist_mat, const float* adj_mat, float* logits,
                     int8_t* bond, int B, void* stream);
-int mcg_gcn_check(mcg_gcn* g);   /* non-zero if an element id outside [0,36) was seen */
+int mcg_gcn_check(mcg_gcn* g);
+/* EDM -> GCN hand-off without RDKit (replaces samples_to_rdkit_mol + prepare_adj_mat_seer_input,
+ * utils/mol_utils.py:18-57,146-194, for the tensor part): elements[B,42] int64 (atomic numbers, 0 padded),
+ * dist_mat[B,42,42] (distances + I), adj_mat[B,42,42] ({0,1} covalent-radius connectivity + I) from
+ * x[B,N,3], h[B,N,8] one-hot and n_nodes[B] (device int32).  Atoms keep their generation order. */
+int mcg_handoff(const float* x, const float* h, const int32_t* n_nodes_dev, int B, int N, float cov_factor,
+                int64_t* elements, float* dist_mat, float* adj_mat, void* stream);   /* non-zero if an element id outside [0,36) was seen */
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,8 @@ from .config import (ATOM_DECODER, CONTEXT_NORMS, DIMENSION, MAX_N_NODES, MIN_N_
                      NUM_BOND_TYPES)
 from .egnn import EGNNDynamics
 from .equivariant_diffusion import EquivariantDiffusion, PredefinedNoiseSchedule
-from .handoff import GeneratedMolecule, assemble_molecules, prepare_adj_mat_seer_input_native
+from .handoff import (GeneratedMolecule, assemble_molecules, prepare_adj_mat_seer_input_hip,
+                      prepare_adj_mat_seer_input_native)
 from .mol_utils import (get_context_shape, ifm_get_xh_from_fragment, ifm_prepare_fragments_for_merge,
                         ifm_prepare_gen_fragment_context, inverse_coord_transform, parse_molblock_heavy_atoms,
                         prepare_edm_input, prepare_fragment)
@@ -170,7 +171,7 @@ class MLConformerGenerator(torch.nn.Module):
         if HAVE_RDKIT:
             from .rdkit_glue import finish_with_rdkit
             return finish_with_rdkit(self, x, h, node_mask, optimise_geometry)
-        el, dm, am = prepare_adj_mat_seer_input_native(x, h, n_nodes, self.dimension)
+        el, dm, am = prepare_adj_mat_seer_input_hip(x, h, n_nodes, self.dimension)
         bond = self.adj_mat_seer.bond_orders(el, dm, am)
         self.last_batch = dict(x=x, h=h, n_nodes=n_nodes, elements=el, bond=bond)
         mols = assemble_molecules(x, el, bond, n_nodes)           # single D2H

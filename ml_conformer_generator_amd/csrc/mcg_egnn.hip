@@ -291,6 +291,9 @@ __global__ __launch_bounds__(64) void k_edge(EdgeArgs p) {
 constexpr int GROUP_FLOATS = 4 * NT * 64;          // 6912 floats = 27 KiB: one 16-k group of B-pack
 constexpr int GROUP_LDS_FLOATS = 28 * 256;         // 7 x 1 KiB pieces per wave x 4 waves = 28 KiB
 constexpr int PD = 6;                              // depth of the B-fragment register ring
+#ifndef MCG_PRIO
+#define MCG_PRIO 0
+#endif
 #ifndef MCG_ABLATE
 #define MCG_ABLATE 0   // measurement builds only: 1 skip epilogue, 2 skip A-gen, 4 skip LDS staging + barriers
 #endif
@@ -306,6 +309,11 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
     const int wave = live ? wave_raw : p.n_waves - 1;
     RowInfo<MT> R;
     edge_decode<MT, EQUIV>(p, wave, live, c, R);
+#if MCG_PRIO == 1
+    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(1);
+#elif MCG_PRIO == 2
+    if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(1);
+#endif
 
     f32x4 acc[MT][NT];
 #pragma unroll

@@ -84,6 +84,24 @@ def prepare_adj_mat_seer_input_native(x: torch.Tensor, h: torch.Tensor, n_nodes:
     return elements, dist_mat, adj_mat
 
 
+def prepare_adj_mat_seer_input_hip(x: torch.Tensor, h: torch.Tensor, n_nodes: torch.Tensor,
+                                   dimension: int = DIMENSION):
+    """Same tensors as `prepare_adj_mat_seer_input_native`, built by ONE HIP launch (`mcg_handoff`)."""
+    from . import _lib
+    if dimension != DIMENSION:
+        raise ValueError("the hand-off kernel is specialised for DIMENSION = 42")
+    B, N, _ = x.shape
+    dev = x.device
+    el = torch.empty(B, dimension, dtype=torch.long, device=dev)
+    dm = torch.empty(B, dimension, dimension, dtype=torch.float32, device=dev)
+    am = torch.empty(B, dimension, dimension, dtype=torch.float32, device=dev)
+    nn = n_nodes.to(dev, torch.int32).contiguous()
+    _lib.check(_lib.lib().mcg_handoff(_lib.dptr(x.contiguous()), _lib.dptr(h.to(torch.float32).contiguous()), _lib.dptr(nn),
+                                      B, N, _COV_FACTOR, _lib.dptr(el), _lib.dptr(dm), _lib.dptr(am),
+                                      _lib.current_stream_ptr(dev)), "mcg_handoff")
+    return el, dm, am
+
+
 def bonds_lower_triangle(bond: torch.Tensor) -> torch.Tensor:
     """`redefine_bonds` reduction (mol_utils.py:210-211): keep the strict lower triangle of the
     argmax, then symmetrise it for the record."""

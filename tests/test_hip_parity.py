@@ -451,3 +451,21 @@ def test_bf16_mode_vs_emulation_and_fp32(edm_sd):
     d.set_precision("f32")
     out32 = d(t.to(DEV), z.to(DEV), nm.to(DEV), em.to(DEV), ctx.to(DEV)).cpu()
     assert float((out32 - ref).abs().max()) / sc < 1e-5
+
+
+def test_handoff_kernel_matches_torch_construction():
+    """mcg_handoff vs the batched torch construction of the same tensors (handoff.py)."""
+    from ml_conformer_generator_amd.handoff import prepare_adj_mat_seer_input_hip, prepare_adj_mat_seer_input_native
+    torch.manual_seed(4)
+    B, N = 9, 27
+    n_nodes = torch.randint(15, 28, (B,))
+    real = (torch.arange(N).unsqueeze(0) < n_nodes.unsqueeze(1)).float().unsqueeze(2)
+    x = torch.cumsum(torch.nn.functional.normalize(torch.randn(B, N, 3), dim=2) * 1.45, dim=1) * real
+    h = torch.nn.functional.one_hot(torch.randint(0, 7, (B, N)), 8).float() * real
+    el0, dm0, am0 = prepare_adj_mat_seer_input_native(x, h, n_nodes)
+    el1, dm1, am1 = prepare_adj_mat_seer_input_hip(x.to(DEV), h.to(DEV), n_nodes)
+    assert torch.equal(el1.cpu(), el0)
+    assert torch.allclose(dm1.cpu(), dm0, rtol=1e-6, atol=1e-6)
+    borderline = ((dm0 - 1.3 * 1.5).abs() < 1e-4)                   # distances within rounding of a threshold
+    assert torch.equal(am1.cpu()[~borderline], am0[~borderline])
+    assert int(am0.sum()) > B * 42                                   # some bonds were actually perceived
