@@ -156,8 +156,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # MCG_DIST_BACKEND=gloo: dry run of the N > 1 control flow with several ranks on ONE GPU
+        backend = os.environ.get("MCG_DIST_BACKEND", "nccl")
+        dev_index = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -216,7 +222,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], dtype=torch.float64,
+                          device=dev if dist.get_backend() == "nccl" else torch.device("cpu"))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

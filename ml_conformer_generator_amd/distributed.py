@@ -43,12 +43,16 @@ def gather_results(local: Dict[str, torch.Tensor], n_samples: int, group=None) -
         return local          # (MCG_FORCE_COLLECTIVE=1: run the collective on a 1-rank group - RCCL smoke check)
     sizes = shard_sizes(n_samples, world)
     cap = max(sizes)
+    # gloo (CPU tests, or a multi-process dry run on one GPU) cannot move device tensors
+    via_host = dist.get_backend(group) == "gloo"
     out = {}
     for key, t in local.items():
-        pad = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        pad[: t.shape[0]] = t
-        buf = torch.empty((world * cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        src = t.cpu() if via_host else t
+        pad = torch.zeros((cap,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        pad[: src.shape[0]] = src
+        buf = torch.empty((world * cap,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
         dist.all_gather_into_tensor(buf, pad.contiguous(), group=group)
         parts = [buf[r * cap: r * cap + sizes[r]] for r in range(world)]
-        out[key] = torch.cat(parts, dim=0)
+        full = torch.cat(parts, dim=0)
+        out[key] = full.to(t.device) if via_host else full
     return out
