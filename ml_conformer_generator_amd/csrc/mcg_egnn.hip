@@ -128,7 +128,7 @@ __device__ __forceinline__ void edge_decode(const EdgeArgs& p, int wave, bool li
 // Epilogue shared by both edge kernels.  C/D layout: column = 16*nt + c, row = 4*g + r of tile mt.
 template <int MT, bool EQUIV>
 __device__ __forceinline__ void edge_epilogue(const EdgeArgs& p, int wave, bool live, int lane, f32x4 (&acc)[MT][NT],
-                                              const RowInfo<MT>& R) {
+                                              const RowInfo<MT>& R, const float* b2p, const float* wvp) {
     const int g = lane >> 4, c = lane & 15;
     float part[MT][4];
 #pragma unroll
@@ -137,8 +137,8 @@ __device__ __forceinline__ void edge_epilogue(const EdgeArgs& p, int wave, bool 
         for (int r = 0; r < 4; ++r) part[mt][r] = 0.f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const float b2 = p.b2[nt * 16 + c];
-        const float wv = p.wv[nt * 16 + c];
+        const float b2 = b2p[nt * 16 + c];
+        const float wv = wvp[nt * 16 + c];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64) void k_edge(EdgeArgs p) {
             for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mcg_mfma(a1[mt], b, acc[mt][nt]);
         }
     }
-    edge_epilogue<MT, EQUIV>(p, wave, true, lane, acc, R);
+    edge_epilogue<MT, EQUIV>(p, wave, true, lane, acc, R, p.b2, p.wv);
 }
 
 // ---- v2: 4 waves per workgroup share the packed W2 through LDS --------------------------------
@@ -300,7 +300,14 @@ constexpr int PD = 6;                              // depth of the B-fragment re
 
 template <int MT, bool EQUIV>
 __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * GROUP_LDS_FLOATS];
+    // two staging buffers + the epilogue's per-column parameters (b2 | wv): ONE array on purpose -
+    // a second __shared__ object makes hipcc drain vmcnt(0) before the staged ds_reads
+    __shared__ __attribute__((aligned(16))) float lds[2 * GROUP_LDS_FLOATS + 2 * HP];
+    for (int i = threadIdx.x; i < HP; i += 256) {
+        lds[2 * GROUP_LDS_FLOATS + i] = p.b2[i];
+        lds[2 * GROUP_LDS_FLOATS + HP + i] = p.wv[i];
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
@@ -462,7 +469,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
         if (sink == 123.456f) p.P[0] = sink;
     }
 #else
-    edge_epilogue<MT, EQUIV>(p, wave, live, lane, acc, R);
+    edge_epilogue<MT, EQUIV>(p, wave, live, lane, acc, R, lds + 2 * GROUP_LDS_FLOATS, lds + 2 * GROUP_LDS_FLOATS + HP);
 #endif
 }
 
@@ -476,7 +483,14 @@ constexpr int PD16 = 4;                            // B-fragment ring depth (4 V
 
 template <bool EQUIV>
 __global__ __launch_bounds__(256, 2) void k_edge_lds_bf16(EdgeArgs p) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * GROUP_LDS_FLOATS];
+    // two staging buffers + the epilogue's per-column parameters (b2 | wv): ONE array on purpose -
+    // a second __shared__ object makes hipcc drain vmcnt(0) before the staged ds_reads
+    __shared__ __attribute__((aligned(16))) float lds[2 * GROUP_LDS_FLOATS + 2 * HP];
+    for (int i = threadIdx.x; i < HP; i += 256) {
+        lds[2 * GROUP_LDS_FLOATS + i] = p.b2[i];
+        lds[2 * GROUP_LDS_FLOATS + HP + i] = p.wv[i];
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
@@ -559,7 +573,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_lds_bf16(EdgeArgs p) {
         }
         a8 = a8n;
     }
-    edge_epilogue<1, EQUIV>(p, wave, live, lane, acc, R);
+    edge_epilogue<1, EQUIV>(p, wave, live, lane, acc, R, lds + 2 * GROUP_LDS_FLOATS, lds + 2 * GROUP_LDS_FLOATS + HP);
 }
 
 // agg[v] = (sum of the per-wave partials that cover node v) / 100   (egnn.py:429-435)

@@ -104,6 +104,22 @@ __global__ __launch_bounds__(256) void mcg_gemm_bf16_kernel(McgGemmArgs p) {
 #pragma unroll
         for (int n = 0; n < RN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // epilogue operands (bias, residual) are fetched NOW so their latency hides under the K loop
+    float ebias[RN];
+    float eres[2][RN][4];
+#pragma unroll
+    for (int n = 0; n < RN; ++n) {
+        const int col = (nt0 + ncl[n]) * 16 + c;
+        ebias[n] = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int orow = row0 + 16 * m + 4 * g + r;
+                eres[m][n][r] = (p.resid && orow < p.M && col < p.n_store) ? p.resid[(size_t)orow * p.ldr + col] : 0.f;
+            }
+    }
+
     const bf16x8* bseg = reinterpret_cast<const bf16x8*>(p.Bp);
 #pragma unroll 1
     for (int seg = 0; seg < 2; ++seg) {
@@ -154,7 +170,7 @@ __global__ __launch_bounds__(256) void mcg_gemm_bf16_kernel(McgGemmArgs p) {
         if (!nvalid[n]) continue;
         const int col = (nt0 + n) * 16 + c;
         if (col >= p.n_store) continue;
-        const float bias = p.bias ? p.bias[col] : 0.f;
+        const float bias = ebias[n];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -164,7 +180,7 @@ __global__ __launch_bounds__(256) void mcg_gemm_bf16_kernel(McgGemmArgs p) {
                 float v = acc[m][n][r] + bias;
                 if (p.act == MCG_ACT_SILU) v = mcg_silu(v);
                 else if (p.act == MCG_ACT_RELU) v = fmaxf(v, 0.f);
-                if (p.resid) v += p.resid[(size_t)orow * p.ldr + col];
+                v += eres[m][n][r];
                 p.C[(size_t)orow * p.ldc + col] = v;
             }
     }
@@ -202,6 +218,22 @@ __global__ __launch_bounds__(256) void mcg_gemm_kernel(McgGemmArgs p) {
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < RN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // epilogue operands (bias, residual) are fetched NOW so their latency hides under the K loop
+    float ebias[RN];
+    float eres[2][RN][4];
+#pragma unroll
+    for (int n = 0; n < RN; ++n) {
+        const int col = (nt0 + ncl[n]) * 16 + c;
+        ebias[n] = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int orow = row0 + 16 * m + 4 * g + r;
+                eres[m][n][r] = (p.resid && orow < p.M && col < p.n_store) ? p.resid[(size_t)orow * p.ldr + col] : 0.f;
+            }
+    }
 
     const float* bseg = p.Bp;
 #pragma unroll 1
@@ -277,7 +309,7 @@ __global__ __launch_bounds__(256) void mcg_gemm_kernel(McgGemmArgs p) {
         if (!nvalid[n]) continue;
         const int col = (nt0 + n) * 16 + c;
         if (col >= p.n_store) continue;
-        const float bias = p.bias ? p.bias[col] : 0.f;
+        const float bias = ebias[n];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -287,7 +319,7 @@ __global__ __launch_bounds__(256) void mcg_gemm_kernel(McgGemmArgs p) {
                 float v = acc[m][n][r] + bias;
                 if (p.act == MCG_ACT_SILU) v = mcg_silu(v);
                 else if (p.act == MCG_ACT_RELU) v = fmaxf(v, 0.f);
-                if (p.resid) v += p.resid[(size_t)orow * p.ldr + col];
+                v += eres[m][n][r];
                 p.C[(size_t)orow * p.ldc + col] = v;
             }
     }
