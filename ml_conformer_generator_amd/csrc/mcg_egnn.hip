@@ -596,6 +596,38 @@ __global__ __launch_bounds__(128) void k_combine_agg(const float* __restrict__ P
     }
 }
 
+// Same two reductions driven by a per-node table of partial-slot indices built once per plan
+// (node_slots[v][0..7], -1 = unused): one table load instead of a chain of four dependent lookups.
+__global__ __launch_bounds__(128) void k_combine_agg_t(const float* __restrict__ P, const int* __restrict__ node_slots,
+                                                        float* __restrict__ agg) {
+    const int v = blockIdx.x;
+    int sl[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sl[k] = node_slots[v * 8 + k];
+    for (int col = threadIdx.x; col < HP; col += 128) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (sl[k] >= 0) s += P[(size_t)sl[k] * HP + col];
+        agg[(size_t)v * HP + col] = s / NORM;
+    }
+}
+
+__global__ void k_coord_update_t(const float* __restrict__ Px, const int* __restrict__ node_slots, int M,
+                                 float* __restrict__ x) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = idx >> 2, comp = idx & 3;
+    if (v >= M || comp == 3) return;
+    float s = 0.f;
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int sl = node_slots[v * 8 + k];
+        if (sl >= 0) { s += Px[(size_t)sl * 4 + comp]; any = true; }
+    }
+    if (any) x[(size_t)v * 4 + comp] += s / NORM;
+}
+
 // x[v] = x[v] + (sum of partials) / 100   (egnn.py:128-134; node mask is implicit)
 __global__ void k_coord_update(const float* __restrict__ Px, const int* __restrict__ node_mol,
                                const int* __restrict__ node_off, const int* __restrict__ row_off,
@@ -727,7 +759,7 @@ struct mcg_egnn {
 struct mcg_plan {
     int B = 0, N = 0, M = 0, n_rows = 0, n_mtiles = 0, MT = 1, n_waves = 0, n_pslots = 0;
     int *n_nodes = nullptr, *node_off = nullptr, *row_off = nullptr, *tile_mol = nullptr, *wave_nf = nullptr,
-        *wave_poff = nullptr, *node_mol = nullptr;
+        *wave_poff = nullptr, *node_mol = nullptr, *node_slots = nullptr;   // node_slots: [M][8] or null
     float *x = nullptr, *x0 = nullptr, *h = nullptr, *h2 = nullptr, *pab = nullptr, *agg = nullptr, *t1 = nullptr,
           *P = nullptr, *Px = nullptr;
     std::vector<void*> allocs;
@@ -890,8 +922,13 @@ int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s) {
     if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
                      MCG_ACT_NONE, s, lp ? E.pab_Bp16 : nullptr)) return e;
     if (int e = run_edge(pl, E, false, pl->P, s, lp)) return e;
-    hipLaunchKernelGGL(k_combine_agg, dim3(M), dim3(128), 0, s, pl->P, pl->node_mol, pl->node_off, pl->row_off,
-                       pl->n_nodes, pl->wave_nf, pl->wave_poff, 16 * pl->MT, pl->agg);
+    // (reading the partials directly in the node GEMM's A-loader was tried: the 4-way gather costs the
+    //  GEMM as much as the ~6 us combine launch it saves at config 2 and more at config 3)
+    if (pl->node_slots)
+        hipLaunchKernelGGL(k_combine_agg_t, dim3(M), dim3(128), 0, s, pl->P, pl->node_slots, pl->agg);
+    else
+        hipLaunchKernelGGL(k_combine_agg, dim3(M), dim3(128), 0, s, pl->P, pl->node_mol, pl->node_off, pl->row_off,
+                           pl->n_nodes, pl->wave_nf, pl->wave_poff, 16 * pl->MT, pl->agg);
     MCG_HIP(hipGetLastError());
     // node_mlp: h + W4 silu(W3 [h | agg] + b3) + b4   (egnn.py:30-34,66-67)
     if (int e = gemm(pl->h, HP, H, pl->agg, HP, H, Nl.w3_Bp, Nl.b3, nullptr, 0, pl->t1, HP, M, NT, HP, MCG_ACT_SILU, s,
@@ -909,8 +946,11 @@ int run_equiv(const mcg_egnn* m, mcg_plan* pl, int block, hipStream_t s) {
                      MCG_ACT_NONE, s, m->bf16 ? E.pab_Bp16 : nullptr)) return e;
     if (int e = run_edge(pl, E, true, pl->Px, s, m->bf16)) return e;
     const int threads = M * 4;
-    hipLaunchKernelGGL(k_coord_update, dim3((threads + 255) / 256), dim3(256), 0, s, pl->Px, pl->node_mol, pl->node_off,
-                       pl->row_off, pl->n_nodes, pl->wave_nf, pl->wave_poff, 16 * pl->MT, M, pl->x);
+    if (pl->node_slots)
+        hipLaunchKernelGGL(k_coord_update_t, dim3((threads + 255) / 256), dim3(256), 0, s, pl->Px, pl->node_slots, M, pl->x);
+    else
+        hipLaunchKernelGGL(k_coord_update, dim3((threads + 255) / 256), dim3(256), 0, s, pl->Px, pl->node_mol, pl->node_off,
+                           pl->row_off, pl->n_nodes, pl->wave_nf, pl->wave_poff, 16 * pl->MT, M, pl->x);
     MCG_HIP(hipGetLastError());
     return MCG_OK;
 }
@@ -1044,7 +1084,24 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
         }
         p->n_pslots = wave_poff[p->n_waves];
     }
+    // per-node partial-slot table (ascending wave order = the order the sums are taken in)
+    std::vector<int> node_slots((size_t)p->M * 8, -1);
+    bool slots_ok = true;
+    for (int b = 0; b < B && slots_ok; ++b) {
+        const int n = nn[b];
+        for (int i = 0; i < n && n > 1; ++i) {
+            const int v = node_off[b] + i;
+            const int first = row_off[b] + i * (n - 1);
+            const int w_lo = first / R, w_hi = (first + n - 2) / R;
+            if (w_hi - w_lo + 1 > 8) { slots_ok = false; break; }
+            for (int w = w_lo; w <= w_hi; ++w) node_slots[(size_t)v * 8 + (w - w_lo)] = wave_poff[w] + v - wave_nf[w];
+        }
+    }
     int e = 0;
+    if (slots_ok && p->M > 0) {
+        e |= upload_i(node_slots, &p->node_slots);
+        p->allocs.push_back(p->node_slots);
+    }
     e |= upload_i(nn, &p->n_nodes); e |= upload_i(node_off, &p->node_off); e |= upload_i(row_off, &p->row_off);
     e |= upload_i(tile_mol, &p->tile_mol); e |= upload_i(wave_nf, &p->wave_nf); e |= upload_i(wave_poff, &p->wave_poff);
     e |= upload_i(node_mol, &p->node_mol);
