@@ -514,3 +514,18 @@ def test_full_sampler_determinism_config2(sampler_factory):
     assert float((outs[0][1].sum(2) - 1).abs().max()) == 0.0
     # centre of gravity of every molecule stays at the origin up to fp32 noise of the final noise add
     assert float(outs[0][0].mean(1).abs().max()) < 1e-2 * float(outs[0][0].abs().max())
+
+
+def test_config2_full_batch_one_call_vs_oracle(dyn, edm_sd):
+    """BASELINE configs[1] at FULL size (64 molecules x 27 atoms = 44 928 real edges): one denoiser call of
+    the HIP path against the CPU oracle on every element (the oracle needs ~6 s for this on 16 threads)."""
+    from oracle import egnn_oracle as EO
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    nm, z, ctx, t = _c2_inputs(seed=21)
+    B, n, _ = z.shape
+    em = edge_mask_of(nm)
+    ref = EO.egnn_dynamics(edm_sd, t.reshape(B, 1), z, nm, em, ctx)
+    plan = dyn.plan(torch.full((B,), n, dtype=torch.int32), n)
+    out = dyn.run(plan, t.to(DEV), z.to(DEV), ctx.to(DEV)).cpu()
+    ok, err, sc = close(out, ref)
+    assert ok, f"err {err} scale {sc}"
