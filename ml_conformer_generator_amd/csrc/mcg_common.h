@@ -80,6 +80,17 @@ __device__ __forceinline__ bf16x8 mcg_pack_bf16(const f32x4& lo, const f32x4& hi
     return r;
 }
 
+// logical work index for hardware workgroup `b` of an `n`-workgroup grid such that the workgroups
+// of one XCD (b % 8) cover a contiguous logical range; bijective for any n
+__device__ __forceinline__ int mcg_xcd_remap(int b, int n) {
+#ifdef MCG_NO_XCD_REMAP
+    return b;
+#else
+    const int q = n >> 3, r = n & 7, xcd = b & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+#endif
+}
+
 // sum over the 16 lanes that share (lane >> 4): xor-butterfly inside a 16-lane row
 __device__ __forceinline__ float mcg_row16_sum(float v) {
     v += __shfl_xor(v, 1, 64);

@@ -311,7 +311,12 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
-    const int wave_raw = blockIdx.x * 4 + wid;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order; speed only, any
+    // other placement is merely slower).  Remapping so that each XCD owns a CONTIGUOUS range of edge
+    // tiles keeps the ~11 workgroups that share one molecule's Pab rows on one L2 (bijective form
+    // for grids that are not a multiple of 8).
+    const int wg = mcg_xcd_remap(blockIdx.x, gridDim.x);
+    const int wave_raw = wg * 4 + wid;
     const bool live = wave_raw < p.n_waves;
     const int wave = live ? wave_raw : p.n_waves - 1;
     RowInfo<MT> R;
@@ -494,7 +499,8 @@ __global__ __launch_bounds__(256, 2) void k_edge_lds_bf16(EdgeArgs p) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
-    const int wave_raw = blockIdx.x * 4 + wid;
+    const int wg = mcg_xcd_remap(blockIdx.x, gridDim.x);
+    const int wave_raw = wg * 4 + wid;
     const bool live = wave_raw < p.n_waves;
     const int wave = live ? wave_raw : p.n_waves - 1;
     RowInfo<1> R;
