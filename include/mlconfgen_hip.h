@@ -40,7 +40,7 @@ int mcg_egnn_set_precision(mcg_egnn* m, int bf16);
 
 /* ---- Batch plan.  Replaces the per-call `get_adj_matrix` edge-list rebuild (egnn.py:475,515-541)
  * and the node/edge masks (mol_utils.py:226-252): node_mask[b] is the prefix of n_nodes_host[b]
- * ones, edge_mask = outer product minus diagonal.  edge_mt: 0 = auto, 1..3 = rows/16 per wave. */
+ * ones, edge_mask = outer product minus diagonal.  edge_mt: 0 = auto, 1..2 = rows/16 per wave. */
 int mcg_plan_create(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_plan** out);
 void mcg_plan_destroy(mcg_plan* p);
 /* info[8] = {real nodes, real edges, edge_mt, edge waves, partial slots, B, N, 16-row edge tiles} */

@@ -901,8 +901,7 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
     }
     switch (pl->MT) {
         case 1: launch_edge<1>(equiv, a, pl->n_waves, s); break;
-        case 2: launch_edge<2>(equiv, a, pl->n_waves, s); break;
-        default: launch_edge<3>(equiv, a, pl->n_waves, s); break;
+        default: launch_edge<2>(equiv, a, pl->n_waves, s); break;
     }
     MCG_HIP(hipGetLastError());
     return MCG_OK;
@@ -1058,10 +1057,10 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
     p->n_mtiles = (p->n_rows + 15) / 16;
     // rows per wave: 16 (MT = 1) keeps the LDS-staged edge kernel at 2 workgroups per CU (2 waves per
     // SIMD cover each other's barrier / epilogue bubbles); measured faster than MT = 2 at configs 2 and 3.
-    // MT = 2, 3 stay selectable for experiments (MT = 3 needs 324 accumulators: hipcc spills it).
+    // MT = 2 stays selectable for experiments (MT = 3 needs 324 accumulators: hipcc spills it - removed).
     int best = 1;
-    if (edge_mt >= 1 && edge_mt <= 3) best = edge_mt;
-    if (const char* e = getenv("MCG_EDGE_MT")) { const int v = atoi(e); if (v >= 1 && v <= 3) best = v; }
+    if (edge_mt >= 1 && edge_mt <= 2) best = edge_mt;
+    if (const char* e = getenv("MCG_EDGE_MT")) { const int v = atoi(e); if (v >= 1 && v <= 2) best = v; }
     p->MT = best;
     p->n_waves = (p->n_mtiles + best - 1) / best;
     const int R = 16 * best;

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from . import _lib
 from .config import N_ATOM_CLASSES, NORM_VALUES
 from .egnn import BatchPlan, EGNNDynamics, sizes_from_node_mask
-from .schedule import gamma_table
+from .schedule import gamma_table, step_scalars
 
 
 class PredefinedNoiseSchedule(torch.nn.Module):
@@ -45,6 +45,7 @@ class EquivariantDiffusion(torch.nn.Module):
         self.norm_values = norm_values
         self.noise_fn: Optional[Callable] = None     # tests inject a recorded noise tape here
         self.trace: Optional[List[torch.Tensor]] = None
+        self._scalar_cache = {}
 
     @property
     def device(self) -> torch.device:
@@ -68,13 +69,15 @@ class EquivariantDiffusion(torch.nn.Module):
         return self.gamma(t)
 
     def _step_scalars(self, s_int: int):
-        """(alpha_ts, c_eps, c_noise) of sample_p_zs_given_zt (:305-326) as python floats (fp32 values)."""
-        g_s, g_t = self._g(s_int), self._g(s_int + 1)
-        sigma2_ts = 1 - torch.exp(F.softplus(g_s) - F.softplus(g_t))
-        alpha_ts = torch.exp(0.5 * (F.logsigmoid(-g_t) - F.logsigmoid(-g_s)))
-        sigma_ts = torch.sqrt(sigma2_ts)
-        sigma_s, sigma_t = torch.sqrt(torch.sigmoid(g_s)), torch.sqrt(torch.sigmoid(g_t))
-        return (float(alpha_ts), float(sigma2_ts / alpha_ts / sigma_t), float(sigma_ts * sigma_s / sigma_t))
+        """(alpha_ts, c_eps, c_noise) of sample_p_zs_given_zt (:305-326) as python floats (fp32 values);
+        cached per (schedule, step): they depend on nothing else."""
+        key = (id(self.gamma), self.T, s_int)
+        hit = self._scalar_cache.get(key)
+        if hit is None:
+            a, c_eps, c_noise, _, _ = step_scalars(self.gamma.gamma.detach(), s_int, self.T)
+            hit = (float(a), float(c_eps), float(c_noise))
+            self._scalar_cache[key] = hit
+        return hit
 
     def _alpha_sigma(self, level_int: int):
         g = self._g(level_int)
