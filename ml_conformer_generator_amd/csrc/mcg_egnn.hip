@@ -776,6 +776,13 @@ struct mcg_plan {
     std::vector<hipStream_t> streams;
     std::vector<hipEvent_t> ev_join;
     hipEvent_t ev_fork = nullptr;
+    // the whole denoiser call (~120 launches) captured once as a HIP graph and replayed: the host then
+    // issues one graph launch per call instead of ~120 kernel launches
+    float* t_buf = nullptr;                 // fixed device copy of t[B] read by the captured graph
+    hipStream_t cap_stream = nullptr;       // capture happens here (the caller's stream may be the null stream)
+    hipGraphExec_t graph_exec = nullptr;
+    const void* g_key[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // xh, context, out, model, bf16
+    int graph_failed = 0;
 };
 
 namespace {
@@ -1129,6 +1136,8 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
 
 void mcg_plan_destroy(mcg_plan* p) {
     if (!p) return;
+    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+    if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     for (mcg_plan* q : p->subs) mcg_plan_destroy(q);
     for (hipStream_t st : p->streams) (void)hipStreamDestroy(st);
     for (hipEvent_t e : p->ev_join) (void)hipEventDestroy(e);
@@ -1140,6 +1149,9 @@ void mcg_plan_destroy(mcg_plan* p) {
 int mcg_plan_create(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_plan** out) {
     if (int e = plan_create_single(B, N, n_nodes_host, edge_mt, out)) return e;
     mcg_plan* p = *out;
+    MCG_HIP(hipMalloc((void**)&p->t_buf, (size_t)B * sizeof(float)));
+    p->allocs.push_back(p->t_buf);
+    MCG_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
     // Split the batch into `parts` molecule ranges of ~equal edge count, one HIP stream each.
     // Measured (tools/bench_kernels.py): 2 ranges are 7 % faster at config 3 (12 k edge tiles = 12 rounds
     // of the chip) but 12 % slower at config 2 (2.8 k tiles: halving them wrecks the tile quantisation),
@@ -1179,19 +1191,16 @@ int mcg_plan_info(const mcg_plan* p, int32_t* info /*[8]*/) {
     return MCG_OK;
 }
 
-// out[B,N,11] = EGNNDynamics.forward(t[B], xh[B,N,11], node_mask==prefix(n_nodes), context[B,N,3])
-int mcg_egnn_dynamics(const mcg_egnn* m, mcg_plan* pl, const float* t, const float* xh, const float* context,
-                      float* out, void* stream) {
-    if (!m || !pl || !t || !xh || !context || !out) { mcg_set_error("mcg_egnn_dynamics: null argument"); return MCG_ERR_ARG; }
-    hipStream_t s = (hipStream_t)stream;
+static int dynamics_launch(const mcg_egnn* m, mcg_plan* pl, const float* t, const float* xh, const float* context,
+                           float* out, hipStream_t s) {
     if (!pl->subs.empty()) {
         // fork: every molecule range runs the whole denoiser on its own stream, join back on `s`
         MCG_HIP(hipEventRecord(pl->ev_fork, s));
         for (size_t k = 0; k < pl->subs.size(); ++k) {
             const size_t b0 = (size_t)pl->sub_b0[k];
             MCG_HIP(hipStreamWaitEvent(pl->streams[k], pl->ev_fork, 0));
-            if (int e = mcg_egnn_dynamics(m, pl->subs[k], t + b0, xh + b0 * pl->N * 11, context + b0 * pl->N * 3,
-                                          out + b0 * pl->N * 11, (void*)pl->streams[k])) return e;
+            if (int e = dynamics_launch(m, pl->subs[k], t + b0, xh + b0 * pl->N * 11, context + b0 * pl->N * 3,
+                                        out + b0 * pl->N * 11, pl->streams[k])) return e;
             MCG_HIP(hipEventRecord(pl->ev_join[k], pl->streams[k]));
             MCG_HIP(hipStreamWaitEvent(s, pl->ev_join[k], 0));
         }
@@ -1207,6 +1216,47 @@ int mcg_egnn_dynamics(const mcg_egnn* m, mcg_plan* pl, const float* t, const flo
     hipLaunchKernelGGL(k_output, dim3(pl->B), dim3(512), 0, s, pl->h, pl->x, pl->x0, pl->n_nodes, pl->node_off, pl->N,
                        m->out_w, m->out_b, out);
     MCG_HIP(hipGetLastError());
+    return MCG_OK;
+}
+
+// out[B,N,11] = EGNNDynamics.forward(t[B], xh[B,N,11], node_mask==prefix(n_nodes), context[B,N,3])
+int mcg_egnn_dynamics(const mcg_egnn* m, mcg_plan* pl, const float* t, const float* xh, const float* context,
+                      float* out, void* stream) {
+    if (!m || !pl || !t || !xh || !context || !out) { mcg_set_error("mcg_egnn_dynamics: null argument"); return MCG_ERR_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    static int use_graph = -1;
+    if (use_graph < 0) { const char* e = getenv("MCG_GRAPH"); use_graph = (e && atoi(e) == 0) ? 0 : 1; }
+    if (!use_graph || pl->graph_failed || !pl->t_buf || !pl->cap_stream) return dynamics_launch(m, pl, t, xh, context, out, s);
+    // t is the only argument that moves between calls of a sampling run: stage it, replay the graph
+    MCG_HIP(hipMemcpyAsync(pl->t_buf, t, (size_t)pl->B * sizeof(float), hipMemcpyDeviceToDevice, s));
+    const void* key[5] = {xh, context, out, m, m->bf16 ? (const void*)1 : nullptr};
+    if (pl->graph_exec && memcmp(key, pl->g_key, sizeof(key)) == 0) {
+        MCG_HIP(hipGraphLaunch(pl->graph_exec, s));
+        return MCG_OK;
+    }
+    if (pl->graph_exec) { (void)hipGraphExecDestroy(pl->graph_exec); pl->graph_exec = nullptr; }
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        pl->graph_failed = 1;
+        if (getenv("MCG_VERBOSE")) fprintf(stderr, "[mcg] hipStreamBeginCapture failed: plain launches\n");
+        return dynamics_launch(m, pl, t, xh, context, out, s);
+    }
+    const int rc = dynamics_launch(m, pl, pl->t_buf, xh, context, out, pl->cap_stream);
+    const hipError_t ce = hipStreamEndCapture(pl->cap_stream, &graph);
+    if (rc != MCG_OK || ce != hipSuccess || !graph ||
+        hipGraphInstantiate(&pl->graph_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (graph) (void)hipGraphDestroy(graph);
+        pl->graph_exec = nullptr;
+        pl->graph_failed = 1;                  // fall back to plain launches for this plan
+        if (getenv("MCG_VERBOSE")) fprintf(stderr, "[mcg] graph capture failed (rc=%d, end=%d): plain launches\n", rc, (int)ce);
+        return dynamics_launch(m, pl, t, xh, context, out, s);
+    }
+    (void)hipGraphDestroy(graph);
+    if (getenv("MCG_VERBOSE")) fprintf(stderr, "[mcg] denoiser call captured as a HIP graph (B=%d)\n", pl->B);
+    memcpy(pl->g_key, key, sizeof(key));
+    MCG_HIP(hipGraphLaunch(pl->graph_exec, s));
     return MCG_OK;
 }
 
