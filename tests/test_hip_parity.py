@@ -529,3 +529,25 @@ def test_config2_full_batch_one_call_vs_oracle(dyn, edm_sd):
     out = dyn.run(plan, t.to(DEV), z.to(DEV), ctx.to(DEV)).cpu()
     ok, err, sc = close(out, ref)
     assert ok, f"err {err} scale {sc}"
+
+
+def test_generator_loads_reference_format_checkpoint_files(edm_sd, gcn_sd, tmp_path):
+    """`torch.save({"state_dict": ...})` files, as the reference ships them (conformer_generator.py:90-102),
+    through the path-based constructor; `__call__` == `generate_conformers` (same positional order)."""
+    from ml_conformer_generator_amd import MLConformerGenerator
+    e, g = tmp_path / "edm.pt", tmp_path / "seer.pt"
+    torch.save({"state_dict": edm_sd}, e)
+    torch.save({"state_dict": gcn_sd}, g)
+    gen = MLConformerGenerator(diffusion_steps=6, device=DEV, edm_weights=str(e), adj_mat_seer_weights=str(g))
+    ctx = torch.tensor([53.6424, 108.3042, 151.4399])
+    torch.manual_seed(1); torch.cuda.manual_seed(1)
+    a = gen.generate_conformers(None, 3, 1, ctx, 20)
+    xa = gen.last_batch["x"].clone()
+    torch.manual_seed(1); torch.cuda.manual_seed(1)
+    b = gen(None, 3, 1, ctx, 20)
+    assert torch.equal(xa, gen.last_batch["x"]) and len(a) == len(b)
+    assert gen.last_batch["bond"].dtype == torch.int8 and tuple(gen.last_batch["bond"].shape) == (3, 42, 42)
+    bad = dict(edm_sd)
+    bad.pop("dynamics.egnn.e_block_4.gcl_1.att_mlp.0.bias")
+    with pytest.raises(RuntimeError, match="Missing key"):
+        MLConformerGenerator(diffusion_steps=6, device=DEV, edm_weights=bad, adj_mat_seer_weights=gcn_sd)
