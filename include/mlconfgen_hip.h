@@ -113,6 +113,16 @@ int mcg_gcn_check(mcg_gcn* g);
 int mcg_handoff(const float* x, const float* h, const int32_t* n_nodes_dev, int B, int N, float cov_factor,
                 int64_t* elements, float* dist_mat, float* adj_mat, void* stream);   /* non-zero if an element id outside [0,36) was seen */
 
+/* ---- Evaluation (grid half): Gaussian-volume shape Tanimoto of one reference against B
+ * candidates in R orientations - `tanimoto_score` (cheminformatics/shape_similarity.py:468-492) for every
+ * (candidate, rotation) pair of `evaluate_samples` (cheminformatics/pipeline.py:64-85).
+ * ref[n_ref,3]; cand[B,N,3] with n_nodes[B] real atoms; rot[R,9] row-major matrices applied as coord @ M;
+ * axes[3,n] = the three linspace axes of the n^3 grid (built by the caller exactly as the reference's
+ * `Grid`); f_scratch[n^3]; score[B*R]. */
+int mcg_shape_tanimoto(const float* ref, int n_ref, const float* cand, const int32_t* n_nodes_dev, int B, int N,
+                       const float* rot, int R, const float* axes, int n, float alpha, float amplitude,
+                       float* f_scratch, float* score, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

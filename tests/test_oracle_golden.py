@@ -120,3 +120,18 @@ def test_adj_mat_seer(gcn_sd):
     assert torch.allclose(logits, g["logits"], rtol=1e-5, atol=1e-5), float((logits - g["logits"]).abs().max())
     assert torch.equal(torch.argmax(logits, -1), g["argmax"])
     assert torch.equal(logits, logits.transpose(1, 2))
+
+
+def test_shape_tanimoto_oracle_matches_reference():
+    import numpy as np
+    from oracle import shape_oracle as SO
+    g = load_golden("shape_tanimoto.npz")
+    assert abs(SO.ALPHA - float(g["alpha"])) < 1e-15
+    pi = torch.pi
+    angs = (torch.tensor([pi, 0, 0]), torch.tensor([0, pi, 0]), torch.tensor([0, 0, pi]))
+    for key in ("ceyyag__yibfeu", "ceyyag__ceyyag", "yibfeu__paba", "crown_6__ceyyag"):
+        a, b = key.split("__")
+        xa, xb = g["xyz_" + a], g["xyz_" + b]
+        mine = [SO.tanimoto_score(xa, xb)] + [SO.tanimoto_score(xa, SO.rotate_coord(xb, ang)) for ang in angs]
+        assert np.abs(np.array(mine) - g[key].numpy()).max() < 1e-7, key
+    assert abs(SO.tanimoto_score(g["xyz_ceyyag"], g["xyz_ceyyag"]) - 1.0) < 1e-6

@@ -251,6 +251,23 @@ def main():
          frag_node_mask=f_nm, frag_edge_mask_sum=f_em.sum(), frag_context=f_ctx, shift=shift, rotation=rot,
          xg=xg, hg=hg, xg_back=xg_back, z_known=zk2, fixed_mask=fm2, moi_shift=moi_shift)
 
+    # 6c. shape Tanimoto (grid part): the reference module needs only numpy + torch
+    ss = importlib.import_module("mlconfgen.cheminformatics.shape_similarity")
+    mols = {}
+    for name in ("ceyyag", "yibfeu", "paba", "crown_6"):
+        xyz, _ = parse_molblock_heavy_atoms(open(f"/root/reference/assets/demo_files/{name}.mol").read())
+        mols[name] = xyz - xyz.mean(0)
+    pi = torch.pi
+    angs = [torch.tensor([0.0, 0.0, 0.0]), torch.tensor([pi, 0, 0]), torch.tensor([0, pi, 0]), torch.tensor([0, 0, pi])]
+    tan = {}
+    for a, b in (("ceyyag", "yibfeu"), ("ceyyag", "ceyyag"), ("yibfeu", "paba"), ("crown_6", "ceyyag")):
+        scores = []
+        for k, ang in enumerate(angs):
+            cb = mols[b] if k == 0 else ss.rotate_coord(coord=mols[b], angles=ang)
+            scores.append(ss.tanimoto_score(mols[a], cb))
+        tan[f"{a}__{b}"] = torch.tensor(scores, dtype=torch.float64)
+    save("shape_tanimoto.npz", alpha=ss.ALPHA, **{f"xyz_{k}": v for k, v in mols.items()}, **tan)
+
     # 7. AdjMatSeer (a15), synthetic weights seed 4321
     gsd = W.synth_adj_mat_seer_state_dict(4321)
     gcn = ams.AdjMatSeer(dimension=42, n_hidden=2048, embedding_dim=64, num_embeddings=36, num_bond_types=5).eval()
