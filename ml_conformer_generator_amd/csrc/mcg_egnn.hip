@@ -295,7 +295,7 @@ constexpr int PD = 6;                              // depth of the B-fragment re
 #define MCG_PRIO 0
 #endif
 #ifndef MCG_ABLATE
-#define MCG_ABLATE 0   // measurement builds only: 1 skip epilogue, 2 skip A-gen, 4 skip LDS staging + barriers
+#define MCG_ABLATE 0   // measurement builds only: 1 skip epilogue, 2 skip A-gen math, 4 skip LDS staging + barriers, 8 skip A loads (bf16)
 #endif
 
 template <int MT, bool EQUIV>
@@ -387,7 +387,12 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
     for (int q = 0; q < NG; ++q) {
         const int buf = q & 1;
 #if !(MCG_ABLATE & 4)
-        asm volatile("s_barrier" ::: "memory");                    // (A) buffer buf^1 is free again
+        // ONE barrier per group.  The DMA of group q was issued a whole group (~3.5k cycles of MFMA
+        // work) ago and this wave's mid-loop operand wait has drained the vector-memory queue since,
+        // so "my pieces of group q have landed" is already true here; after the barrier it is true
+        // for every wave, and every wave has also finished reading buffer buf^1 (group q-1).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
 #endif
         // A-operand inputs of the NEXT group (or of the tail step) - ordinary loads, issued first
         f32x4 va[MT], vb[MT], wdv, w0v;
@@ -410,9 +415,6 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
         }
 #if !(MCG_ABLATE & 4)
         stage(q + 1, buf ^ 1);                                     // group q+1 (the tail group when q+1 == NG)
-        // my pieces of group q have landed once at most the loads issued above are outstanding
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 + 2 * MT + 2) : "memory");
-        asm volatile("s_barrier" ::: "memory");                    // (B) everybody's pieces of group q landed
 #endif
         const float* lb = lds + buf * GROUP_LDS_FLOATS + lane;
         f32x4 a4n[MT];
@@ -486,10 +488,8 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
 constexpr int KB16 = (H + 31) / 32;                // 14
 constexpr int PD16 = 4;                            // B-fragment ring depth (4 VGPRs per fragment)
 
-template <bool EQUIV>
-__global__ __launch_bounds__(256, 2) void k_edge_lds_bf16(EdgeArgs p) {
-    // two staging buffers + the epilogue's per-column parameters (b2 | wv): ONE array on purpose -
-    // a second __shared__ object makes hipcc drain vmcnt(0) before the staged ds_reads
+template <int MT, bool EQUIV>
+__global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds_bf16(EdgeArgs p) {
     __shared__ __attribute__((aligned(16))) float lds[2 * GROUP_LDS_FLOATS + 2 * HP];
     for (int i = threadIdx.x; i < HP; i += 256) {
         lds[2 * GROUP_LDS_FLOATS + i] = p.b2[i];
@@ -503,15 +503,22 @@ __global__ __launch_bounds__(256, 2) void k_edge_lds_bf16(EdgeArgs p) {
     const int wave_raw = wg * 4 + wid;
     const bool live = wave_raw < p.n_waves;
     const int wave = live ? wave_raw : p.n_waves - 1;
-    RowInfo<1> R;
-    edge_decode<1, EQUIV>(p, wave, live, c, R);
+    RowInfo<MT> R;
+    edge_decode<MT, EQUIV>(p, wave, live, c, R);
 
-    f32x4 acc[1][NT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const float* pa = p.pab + (size_t)R.ni[0] * (2 * HP) + 8 * g;
-    const float* pb = p.pab + (size_t)R.nj[0] * (2 * HP) + HP + 8 * g;
+    const float* pa[MT];
+    const float* pb[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        pa[mt] = p.pab + (size_t)R.ni[mt] * (2 * HP) + 8 * g;
+        pb[mt] = p.pab + (size_t)R.nj[mt] * (2 * HP) + HP + 8 * g;
+    }
     const float* wdp = p.wd + 8 * g;
     const float* w0p = p.wd0 + 8 * g;
 
@@ -526,60 +533,105 @@ __global__ __launch_bounds__(256, 2) void k_edge_lds_bf16(EdgeArgs p) {
                                                      lane * 16, (q * GROUP_FLOATS + piece * 256) * 4, 0, 0);
         }
     };
-    auto agen = [&](const f32x4 (&v)[8]) -> bf16x8 {     // v = {pa0,pa1,pb0,pb1,wd0,wd1,w00,w01}
-        f32x4 lo, hi;
+    // v[mt] = {pa0,pa1,pb0,pb1}; w = {wd0,wd1,w00,w01}
+    auto agen = [&](const f32x4 (&v)[MT][4], const f32x4 (&w)[4], bf16x8 (&a8)[MT]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            lo[j] = mcg_silu(fmaf(v[6][j], R.d02[0], fmaf(v[4][j], R.d2[0], v[0][j] + v[2][j])));
-            hi[j] = mcg_silu(fmaf(v[7][j], R.d02[0], fmaf(v[5][j], R.d2[0], v[1][j] + v[3][j])));
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 lo, hi;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lo[j] = mcg_silu(fmaf(w[2][j], R.d02[mt], fmaf(w[0][j], R.d2[mt], v[mt][0][j] + v[mt][2][j])));
+                hi[j] = mcg_silu(fmaf(w[3][j], R.d02[mt], fmaf(w[1][j], R.d2[mt], v[mt][1][j] + v[mt][3][j])));
+            }
+            a8[mt] = mcg_pack_bf16(lo, hi);
         }
-        return mcg_pack_bf16(lo, hi);
     };
-    auto load_a = [&](int kb, f32x4 (&v)[8]) {
-        v[0] = *reinterpret_cast<const f32x4*>(pa + 32 * kb);  v[1] = *reinterpret_cast<const f32x4*>(pa + 32 * kb + 4);
-        v[2] = *reinterpret_cast<const f32x4*>(pb + 32 * kb);  v[3] = *reinterpret_cast<const f32x4*>(pb + 32 * kb + 4);
-        v[4] = *reinterpret_cast<const f32x4*>(wdp + 32 * kb); v[5] = *reinterpret_cast<const f32x4*>(wdp + 32 * kb + 4);
-        v[6] = *reinterpret_cast<const f32x4*>(w0p + 32 * kb); v[7] = *reinterpret_cast<const f32x4*>(w0p + 32 * kb + 4);
+    auto load_a = [&](int kb, f32x4 (&v)[MT][4], f32x4 (&w)[4]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            v[mt][0] = *reinterpret_cast<const f32x4*>(pa[mt] + 32 * kb);
+            v[mt][1] = *reinterpret_cast<const f32x4*>(pa[mt] + 32 * kb + 4);
+            v[mt][2] = *reinterpret_cast<const f32x4*>(pb[mt] + 32 * kb);
+            v[mt][3] = *reinterpret_cast<const f32x4*>(pb[mt] + 32 * kb + 4);
+        }
+        w[0] = *reinterpret_cast<const f32x4*>(wdp + 32 * kb); w[1] = *reinterpret_cast<const f32x4*>(wdp + 32 * kb + 4);
+        w[2] = *reinterpret_cast<const f32x4*>(w0p + 32 * kb); w[3] = *reinterpret_cast<const f32x4*>(w0p + 32 * kb + 4);
     };
 
     stage(0, 0);
-    bf16x8 a8;
+    bf16x8 a8[MT];
     {
-        f32x4 v[8];
-        load_a(0, v);
-        a8 = agen(v);
+        f32x4 v[MT][4], w[4];
+        load_a(0, v, w);
+        agen(v, w, a8);
     }
 #pragma unroll 1
     for (int kb = 0; kb < KB16; ++kb) {
         const int buf = kb & 1;
-        asm volatile("s_barrier" ::: "memory");                    // (A) buffer buf^1 is free again
-        f32x4 v[8];
+#if !(MCG_ABLATE & 4)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my pieces of block kb (issued one block ago)
+        asm volatile("s_barrier" ::: "memory");                    // all pieces landed + buffer buf^1 free
+#endif
+        f32x4 v[MT][4], w[4];
         const int kn = kb + 1 < KB16 ? kb + 1 : kb;                // (last block: harmless reload)
-        load_a(kn, v);
+#if !(MCG_ABLATE & 8)
+        load_a(kn, v, w);
+#else
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[mt][i] = (f32x4){0.1f, 0.2f, 0.3f, 0.4f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (f32x4){0.1f, 0.2f, 0.3f, 0.4f};
+#endif
+#if !(MCG_ABLATE & 4)
         stage(kn, buf ^ 1);
-        asm volatile("s_waitcnt vmcnt(15)" ::: "memory");          // my 7 pieces of block kb have landed
-        asm volatile("s_barrier" ::: "memory");                    // (B)
+#endif
         const bf16x8* lb = reinterpret_cast<const bf16x8*>(lds + buf * GROUP_LDS_FLOATS) + lane;
         bf16x8 bq[PD16];
 #pragma unroll
         for (int i = 0; i < PD16; ++i) bq[i] = lb[i * 64];
-        bf16x8 a8n;
+        bf16x8 a8n[MT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const bf16x8 b = bq[nt % PD16];
             if (nt + PD16 < NT) bq[nt % PD16] = lb[(nt + PD16) * 64];
-            acc[0][nt] = mcg_mfma_bf16(a8, b, acc[0][nt]);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (nt == NT / 2) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(v[i]));
-                a8n = agen(v);
+            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mcg_mfma_bf16(a8[mt], b, acc[mt][nt]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);
+            if (nt == (MT == 1 ? NT / 2 : NT - 4)) {
+                // next block's A operand; with MT = 2 it sits near the END of the block so that the operand
+                // loads (and the DMA issued with them) have had a whole block of MFMA work to land
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(v[mt][i]));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(w[i]));
+#if (MCG_ABLATE & 2)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a8n[mt] = mcg_pack_bf16(v[mt][0] + w[0], v[mt][1] + w[1]);
+#else
+                agen(v, w, a8n);
+#endif
             }
         }
-        a8 = a8n;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a8[mt] = a8n[mt];
     }
-    edge_epilogue<1, EQUIV>(p, wave, live, lane, acc, R, lds + 2 * GROUP_LDS_FLOATS, lds + 2 * GROUP_LDS_FLOATS + HP);
+#if (MCG_ABLATE & 1)
+    {
+        float sink = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) sink += acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2] + acc[mt][nt][3];
+        if (sink == 123.456f) p.P[0] = sink;
+    }
+#else
+    edge_epilogue<MT, EQUIV>(p, wave, live, lane, acc, R, lds + 2 * GROUP_LDS_FLOATS, lds + 2 * GROUP_LDS_FLOATS + HP);
+#endif
 }
 
 // agg[v] = (sum of the per-wave partials that cover node v) / 100   (egnn.py:429-435)
@@ -898,11 +950,16 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
     a.wv = L.wv; a.bv = L.bv; a.n_nodes = pl->n_nodes; a.node_off = pl->node_off; a.row_off = pl->row_off;
     a.B = pl->B; a.tile_mol = pl->tile_mol; a.wave_nf = pl->wave_nf; a.wave_poff = pl->wave_poff;
     a.n_rows = pl->n_rows; a.n_mtiles = pl->n_mtiles; a.n_waves = pl->n_waves; a.P = P;
-    if (bf16 && pl->MT == 1) {
+    if (bf16) {
         a.Bp = reinterpret_cast<const float*>(L.w2_Bp16);
         const int wgs = (pl->n_waves + 3) / 4;
-        if (equiv) hipLaunchKernelGGL((k_edge_lds_bf16<true>), dim3(wgs), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_edge_lds_bf16<false>), dim3(wgs), dim3(256), 0, s, a);
+        if (pl->MT == 1) {
+            if (equiv) hipLaunchKernelGGL((k_edge_lds_bf16<1, true>), dim3(wgs), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_edge_lds_bf16<1, false>), dim3(wgs), dim3(256), 0, s, a);
+        } else {
+            if (equiv) hipLaunchKernelGGL((k_edge_lds_bf16<2, true>), dim3(wgs), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_edge_lds_bf16<2, false>), dim3(wgs), dim3(256), 0, s, a);
+        }
         MCG_HIP(hipGetLastError());
         return MCG_OK;
     }
