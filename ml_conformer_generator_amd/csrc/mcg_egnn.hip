@@ -480,6 +480,174 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
 #endif
 }
 
+// ---- v3: latency variant for SMALL batches - the 4 waves of a workgroup split the 27 column tiles of ONE
+// 16-row edge tile (7,7,7,6).  With fewer than ~1000 tiles in the batch the throughput kernel above leaves
+// most SIMDs idle while each busy one walks a 45 us serial chain (105 k-steps x 27 MFMAs); here the chain is
+// 4x shorter and 4x more SIMDs work.  Costs: W2 is staged once per tile instead of once per 4 tiles (fine
+// while the batch is small), the layer-1 finish is replicated per wave, and the gate / coordinate-head dot
+// product needs one cross-wave exchange through LDS.
+constexpr int NS_T = 7;          // column tiles per wave: nt = wid + 4*i
+
+template <bool EQUIV>
+__global__ __launch_bounds__(256, 2) void k_edge_ns(EdgeArgs p) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * GROUP_LDS_FLOATS + 2 * HP + 64];
+    for (int i = threadIdx.x; i < HP; i += 256) {
+        lds[2 * GROUP_LDS_FLOATS + i] = p.b2[i];
+        lds[2 * GROUP_LDS_FLOATS + HP + i] = p.wv[i];
+    }
+    __syncthreads();
+    const float* b2p = lds + 2 * GROUP_LDS_FLOATS;
+    const float* wvp = b2p + HP;
+    float* xchg = lds + 2 * GROUP_LDS_FLOATS + 2 * HP;          // [4 waves][16 rows] partial dot products
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int wave = mcg_xcd_remap(blockIdx.x, gridDim.x);       // tile index == "wave" index of the MT = 1 plan
+    RowInfo<1> R;
+    edge_decode<1, EQUIV>(p, wave, true, c, R);
+
+    f32x4 acc[NS_T];
+#pragma unroll
+    for (int i = 0; i < NS_T; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* pa = p.pab + (size_t)R.ni[0] * (2 * HP) + 4 * g;
+    const float* pb = p.pab + (size_t)R.nj[0] * (2 * HP) + HP + 4 * g;
+    const float* wdp = p.wd + 4 * g;
+    const float* w0p = p.wd0 + 4 * g;
+
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.Bp), 0, (KSTEPS * NT * 64 + GROUP_LDS_FLOATS) * 4, 0x00020000);
+    auto stage = [&](int q, int buf) {
+        float* dst = lds + buf * GROUP_LDS_FLOATS;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int piece = wid + 4 * i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(brsrc, (__attribute__((address_space(3))) void*)(dst + piece * 256), 16,
+                                                     lane * 16, (q * GROUP_FLOATS + piece * 256) * 4, 0, 0);
+        }
+    };
+    auto agen = [&](const f32x4& va, const f32x4& vb, const f32x4& wdv, const f32x4& w0v) -> f32x4 {
+        f32x4 a;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[s] = mcg_silu(fmaf(w0v[s], R.d02[0], fmaf(wdv[s], R.d2[0], va[s] + vb[s])));
+        return a;
+    };
+
+    stage(0, 0);
+    f32x4 a4 = agen(*reinterpret_cast<const f32x4*>(pa), *reinterpret_cast<const f32x4*>(pb),
+                    *reinterpret_cast<const f32x4*>(wdp), *reinterpret_cast<const f32x4*>(w0p));
+    constexpr int NG = H / 16;
+#pragma unroll 1
+    for (int q = 0; q < NG; ++q) {
+        const int buf = q & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        f32x4 va, vb, wdv, w0v;
+        if (q + 1 < NG) {
+            va = *reinterpret_cast<const f32x4*>(pa + 16 * (q + 1));
+            vb = *reinterpret_cast<const f32x4*>(pb + 16 * (q + 1));
+            wdv = *reinterpret_cast<const f32x4*>(wdp + 16 * (q + 1));
+            w0v = *reinterpret_cast<const f32x4*>(w0p + 16 * (q + 1));
+        } else {
+            va = (f32x4){p.pab[(size_t)R.ni[0] * (2 * HP) + 16 * NG + g], 0.f, 0.f, 0.f};
+            vb = (f32x4){p.pab[(size_t)R.nj[0] * (2 * HP) + HP + 16 * NG + g], 0.f, 0.f, 0.f};
+            wdv = (f32x4){p.wd[16 * NG + g], 0.f, 0.f, 0.f};
+            w0v = (f32x4){p.wd0[16 * NG + g], 0.f, 0.f, 0.f};
+        }
+        stage(q + 1, buf ^ 1);
+        const float* lb = lds + buf * GROUP_LDS_FLOATS + lane + wid * 64;
+        f32x4 a4n;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float bq[NS_T];
+#pragma unroll
+            for (int i = 0; i < NS_T; ++i) bq[i] = lb[(s * NT + 4 * i) * 64];      // tile wid + 4i (i = 6, wid = 3: pad piece)
+#pragma unroll
+            for (int i = 0; i < NS_T; ++i) acc[i] = mcg_mfma(a4[s], bq[i], acc[i]);
+            if (s == 1) {
+                asm volatile("" : "+v"(va), "+v"(vb), "+v"(wdv), "+v"(w0v));
+                a4n = agen(va, vb, wdv, w0v);
+            }
+        }
+        a4 = a4n;
+    }
+    {   // tail k-step from buffer NG & 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        const float* lb = lds + (NG & 1) * GROUP_LDS_FLOATS + lane + wid * 64;
+#pragma unroll
+        for (int i = 0; i < NS_T; ++i) acc[i] = mcg_mfma(a4[0], lb[(4 * i) * 64], acc[i]);
+    }
+
+    // ---- epilogue: own column tiles nt = wid + 4i (the 7th tile of wave 3 is padding)
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NS_T; ++i) {
+        const int nt = wid + 4 * i;
+        if (nt >= NT) continue;
+        const float b2 = b2p[nt * 16 + c], wv = wvp[nt * 16 + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float m = mcg_silu(acc[i][r] + b2);
+            acc[i][r] = m;
+            part[r] = fmaf(wv, m, part[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        part[r] = mcg_row16_sum(part[r]);
+        if (c == 0) xchg[wid * 16 + 4 * g + r] = part[r];
+    }
+    __syncthreads();
+    float dot[4];
+    int rseg[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        dot[r] = ((xchg[row] + xchg[16 + row]) + xchg[32 + row]) + xchg[48 + row];     // fixed wave order
+        rseg[r] = __shfl(R.seg[0], row, 64);
+    }
+    const int nseg = p.wave_poff[wave + 1] - p.wave_poff[wave];
+    const int pbase = p.wave_poff[wave];
+    if (EQUIV) {
+        if (wid != 0) return;
+        float tx[4], ty[4], tz[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * g + r;
+            tx[r] = __shfl(R.ux[0], row, 64) * dot[r];
+            ty[r] = __shfl(R.uy[0], row, 64) * dot[r];
+            tz[r] = __shfl(R.uz[0], row, 64) * dot[r];
+        }
+        for (int s = 0; s < nseg; ++s) {
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (rseg[r] == s) { sx += tx[r]; sy += ty[r]; sz += tz[r]; }
+            sx = mcg_group4_sum(sx); sy = mcg_group4_sum(sy); sz = mcg_group4_sum(sz);
+            if (lane == 0) {
+                float* dst = p.P + (size_t)(pbase + s) * 4;
+                dst[0] = sx; dst[1] = sy; dst[2] = sz; dst[3] = 0.f;
+            }
+        }
+    } else {
+        float sel[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sel[r] = rseg[r] == c ? mcg_sigmoid(dot[r] + p.bv) : 0.f;
+        const int row_seg = 4 * g;
+#pragma unroll
+        for (int i = 0; i < NS_T; ++i) {
+            const int nt = wid + 4 * i;
+            if (nt >= NT) continue;
+            f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) d = mcg_mfma(sel[t], acc[i][t], d);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (row_seg + r < nseg) p.P[(size_t)(pbase + row_seg + r) * HP + nt * 16 + c] = d[r];
+        }
+    }
+}
+
 // ---- v2/bf16: same structure, operands rounded to bf16 (fp32 accumulate, fp32 epilogue) -------------
 // v_mfma_f32_16x16x32_bf16: one k-block of 32 per MFMA, K padded 420 -> 448 with zero weights (the
 // activation reads past column 420 land in finite padding / neighbouring data that the zeros cancel).
@@ -960,6 +1128,17 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
             if (equiv) hipLaunchKernelGGL((k_edge_lds_bf16<2, true>), dim3(wgs), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((k_edge_lds_bf16<2, false>), dim3(wgs), dim3(256), 0, s, a);
         }
+        MCG_HIP(hipGetLastError());
+        return MCG_OK;
+    }
+    // small batches: column-split latency variant (one workgroup per 16-row tile).  Measured per edge launch
+    // (tools/bench_small.py): <= 256 tiles 24 us, <= 512 tiles 36 us vs 53 us for the throughput kernel's
+    // single 16-row chain; beyond 512 tiles the 4x W2 staging traffic makes it slower (59 us at 527 tiles).
+    static int ns_max = -1;
+    if (ns_max < 0) { const char* e = getenv("MCG_NS_MAX_TILES"); ns_max = e ? atoi(e) : 512; }
+    if (pl->MT == 1 && pl->n_mtiles <= ns_max) {
+        if (equiv) hipLaunchKernelGGL((k_edge_ns<true>), dim3(pl->n_mtiles), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_edge_ns<false>), dim3(pl->n_mtiles), dim3(256), 0, s, a);
         MCG_HIP(hipGetLastError());
         return MCG_OK;
     }

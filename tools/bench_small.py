@@ -11,7 +11,7 @@ dyn = EGNNDynamics(device=dev); dyn.load_reference_state_dict(W.synth_edm_state_
 T = 50
 gm = EquivariantDiffusion(dynamics=dyn, in_node_nf=8, timesteps=1000, noise_precision=1e-5)
 gm.gamma = PredefinedNoiseSchedule(timesteps=T, precision=1e-5); gm.T = T
-for B, n in ((4, 19), (16, 27), (40, 27), (64, 27)):
+for B, n in [tuple(int(v) for v in os.environ["MCG_SMALL_SHAPES"].split(",")[i:i+2]) for i in range(0, 2*len(os.environ["MCG_SMALL_SHAPES"].split(","))//2, 2)] if os.environ.get("MCG_SMALL_SHAPES") else ((4, 19), (16, 27), (40, 27), (64, 27)):
     nm = torch.ones(B, n, 1, device=dev); ctx = torch.zeros(B, n, 3, device=dev)
     gm(nm, None, ctx, 0); torch.cuda.synchronize()
     t0 = time.perf_counter(); x, h = gm(nm, None, ctx, 0); t_host = time.perf_counter() - t0
