@@ -43,6 +43,9 @@ int mcg_egnn_set_precision(mcg_egnn* m, int bf16);
  * ones, edge_mask = outer product minus diagonal.  edge_mt: 0 = auto, 1..2 = rows/16 per wave. */
 int mcg_plan_create(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_plan** out);
 void mcg_plan_destroy(mcg_plan* p);
+/* Edge-kernel choice: -1 auto (the column-split latency kernel when the batch has <= 512 edge tiles,
+ * else the throughput kernel), 0 = always throughput, 1 = always latency (needs edge_mt 1). */
+int mcg_plan_set_latency_mode(mcg_plan* p, int mode);
 /* info[8] = {real nodes, real edges, edge_mt, edge waves, partial slots, B, N, 16-row edge tiles} */
 int mcg_plan_info(const mcg_plan* p, int32_t* info_host);
 

@@ -25,6 +25,7 @@ SIGNATURES: Dict[str, tuple] = {
     "mcg_plan_create": (_i, [_i, _i, _vp, _i, _pp]),
     "mcg_plan_destroy": (None, [_vp]),
     "mcg_plan_info": (_i, [_vp, _vp]),
+    "mcg_plan_set_latency_mode": (_i, [_vp, _i]),
     "mcg_egnn_dynamics": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mcg_egnn_block_debug": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "mcg_egnn_gcl_debug": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),

@@ -1003,6 +1003,7 @@ struct mcg_plan {
     hipGraphExec_t graph_exec = nullptr;
     const void* g_key[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // xh, context, out, model, bf16
     int graph_failed = 0;
+    int latency_mode = -1;                  // column-split edge kernel: -1 auto (small batches), 0 never, 1 always
 };
 
 namespace {
@@ -1136,7 +1137,7 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
     // single 16-row chain; beyond 512 tiles the 4x W2 staging traffic makes it slower (59 us at 527 tiles).
     static int ns_max = -1;
     if (ns_max < 0) { const char* e = getenv("MCG_NS_MAX_TILES"); ns_max = e ? atoi(e) : 512; }
-    if (pl->MT == 1 && pl->n_mtiles <= ns_max) {
+    if (pl->MT == 1 && (pl->latency_mode == 1 || (pl->latency_mode < 0 && pl->n_mtiles <= ns_max))) {
         if (equiv) hipLaunchKernelGGL((k_edge_ns<true>), dim3(pl->n_mtiles), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_edge_ns<false>), dim3(pl->n_mtiles), dim3(256), 0, s, a);
         MCG_HIP(hipGetLastError());
@@ -1417,6 +1418,15 @@ int mcg_plan_create(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_
         b0 = b1;
     }
     MCG_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    return MCG_OK;
+}
+
+// mode: -1 auto (column-split latency kernel for <= 512 edge tiles), 0 never, 1 always
+int mcg_plan_set_latency_mode(mcg_plan* p, int mode) {
+    if (!p || mode < -1 || mode > 1) return MCG_ERR_ARG;
+    p->latency_mode = mode;
+    for (mcg_plan* q : p->subs) q->latency_mode = mode;
+    if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }   // re-capture
     return MCG_OK;
 }
 

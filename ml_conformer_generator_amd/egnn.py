@@ -41,6 +41,10 @@ class BatchPlan:
     def handle(self):
         return self._h
 
+    def set_latency_mode(self, mode: int) -> None:
+        """-1 auto, 0 always the throughput edge kernel, 1 always the column-split latency kernel."""
+        _lib.check(_lib.lib().mcg_plan_set_latency_mode(self._h, int(mode)), "mcg_plan_set_latency_mode")
+
     def node_mask(self) -> torch.Tensor:
         idx = torch.arange(self.N).unsqueeze(0)
         return (idx < self.n_nodes_host.unsqueeze(1)).to(torch.float32).unsqueeze(2).to(self.device)

@@ -84,6 +84,22 @@ def test_dynamics_seam_vs_golden(dyn, tag):
     assert float((out.cpu() * (1 - nm)).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("tag", ["b2n20", "b3n39", "b3n27_x30"])
+def test_both_edge_kernels_on_the_golden_shapes(dyn, tag, mode):
+    """The throughput kernel (mode 0) and the column-split latency kernel (mode 1) on the same small golden
+    inputs (auto mode would only pick the latency kernel at these sizes)."""
+    g = load_golden(f"dynamics_{tag}.npz")
+    nm = g["node_mask"]
+    B, N, _ = nm.shape
+    plan = dyn.plan(nm.sum(1).reshape(-1).to(torch.int32), N, edge_mt=1)
+    plan.set_latency_mode(mode)
+    out = dyn.run(plan, g["t"].reshape(B).to(DEV), g["xh"].to(DEV), g["context"].to(DEV))
+    plan.set_latency_mode(-1)
+    ok, err, sc = close(out, g["out"])
+    assert ok, f"mode {mode}: err {err} scale {sc}"
+
+
 @pytest.mark.parametrize("mt", [1, 2])
 def test_dynamics_edge_tilings_agree_with_oracle(dyn, edm_sd, mt):
     """Both rows-per-wave variants of the edge kernel against the oracle on a ragged batch."""
