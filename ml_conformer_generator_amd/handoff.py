@@ -42,6 +42,20 @@ class GeneratedMolecule:
     def GetNumAtoms(self) -> int:          # RDKit-like convenience
         return len(self.atomic_numbers)
 
+    def to_molblock(self, name: str = "generated") -> str:
+        """V2000 MOL block (heavy atoms, bond orders 1/2/3, aromatic = 4) - consumable by RDKit
+        (`Chem.MolFromMolBlock`) or any other toolkit without going through this package."""
+        n = len(self.atomic_numbers)
+        bonds = [(i + 1, j + 1, int(self.bond_orders[i, j])) for i in range(n) for j in range(i)
+                 if int(self.bond_orders[i, j]) != 0]
+        lines = [name, "  mlconfgen-mi355x", "", "%3d%3d  0  0  0  0  0  0  0  0999 V2000" % (n, len(bonds))]
+        for s, c in zip(self.symbols, self.coords.tolist()):
+            lines.append("%10.4f%10.4f%10.4f %-3s 0  0  0  0  0  0  0  0  0  0  0  0" % (c[0], c[1], c[2], s))
+        for i, j, o in bonds:
+            lines.append("%3d%3d%3d  0" % (i, j, o))
+        lines.append("M  END")
+        return "\n".join(lines) + "\n"
+
     def to_xyz_block(self) -> str:
         lines = [f"{len(self.atomic_numbers)}", ""]
         for s, c in zip(self.symbols, self.coords.tolist()):

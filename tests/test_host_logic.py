@@ -123,6 +123,12 @@ def test_native_handoff_shapes_and_proxy():
     assert not valence_proxy_valid(z, bd, 2)
     m = GeneratedMolecule([6, 8], torch.zeros(2, 3), torch.zeros(2, 2, dtype=torch.int8))
     assert m.symbols == ["C", "O"] and m.to_xyz_block().startswith("2\n\nC 0.000000000")
+    bo = torch.tensor([[0, 2, 0], [2, 0, 1], [0, 1, 0]], dtype=torch.int8)
+    m3 = GeneratedMolecule([8, 6, 17], torch.tensor([[0.0, 0, 0], [1.2, 0, 0], [2.1, 1.4, 0]]), bo)
+    blk = m3.to_molblock("t")
+    xyz, zs = MU.parse_molblock_heavy_atoms(blk)                  # round trip through the V2000 parser
+    assert zs == [8, 6, 17] and torch.allclose(xyz, m3.coords, atol=1e-4)
+    assert "  3  2  0" in blk and "  2  1  2  0" in blk and "  3  2  1  0" in blk and blk.rstrip().endswith("M  END")
 
 
 def test_product_never_imports_the_oracle():
