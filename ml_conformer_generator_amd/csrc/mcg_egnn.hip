@@ -802,6 +802,226 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds_bf16(EdgeAr
 #endif
 }
 
+// ---- bf16, 64-row workgroup tiles -------------------------------------------------------------------
+// Every bf16 MFMA eats 2 KiB of operands in 16 cycles; fed one fragment per MFMA from LDS (kernel above) the
+// loop is LDS-read-bound at ~40 % of the matrix pipe.  Here a workgroup owns 64 edge rows (4 row tiles) and
+// its 4 waves split the 27 column tiles (7,7,7,6): a wave's 4x7 grid of accumulators reuses every A fragment
+// 7x and every B fragment 4x from registers (11 fragment reads per 28 MFMAs).  The A operand (layer-1 finish
+// + SiLU, rounded to bf16) of row tile w is produced once by wave w and shared through LDS; the gate /
+// coordinate-head dot product is completed across the waves through LDS in fixed order.
+constexpr int W64_A_FLOATS = 2 * 4 * 64 * 4;          // A tile ring: [2][4 row tiles][64 lanes] x 16 B
+constexpr int W64_LDS_FLOATS = 2 * HP + W64_A_FLOATS + 4 * 64 + 64 * 4;       // no B staging: 13 KB
+
+template <bool EQUIV>
+__global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
+    __shared__ __attribute__((aligned(16))) float lds[W64_LDS_FLOATS];
+    float* const par = lds;                                              // b2 | wv
+    bf16x8* const a_lds = reinterpret_cast<bf16x8*>(par + 2 * HP);       // [2][4][64]
+    float* const xchg = par + 2 * HP + W64_A_FLOATS;                     // [4 waves][64 rows]
+    float* const ri = xchg + 4 * 64;                                     // [64 rows][4]: seg, ux, uy, uz
+    for (int i = threadIdx.x; i < HP; i += 256) { par[i] = p.b2[i]; par[HP + i] = p.wv[i]; }
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int unit = mcg_xcd_remap(blockIdx.x, gridDim.x);               // 64-row unit == "wave" of the MT = 4 plan
+    const int nf = p.wave_nf[unit];
+
+    // rows of MY row tile (tile wid of the unit): A-operand generation + row facts for everybody's epilogue
+    int vi = 0, vj = 0, sg = -1;
+    float d2, d02, ux = 0.f, uy = 0.f, uz = 0.f;
+    {
+        const int tile = unit * 4 + wid;
+        const int r = tile * 16 + c;
+        if (tile < p.n_mtiles && r < p.n_rows) {
+            int b = p.tile_mol[tile];
+            while (r >= p.row_off[b + 1]) ++b;
+            const int n = p.n_nodes[b];
+            const int local = r - p.row_off[b];
+            const int i = local / (n - 1);
+            const int jj = local - i * (n - 1);
+            vi = p.node_off[b] + i;
+            vj = p.node_off[b] + jj + (jj >= i ? 1 : 0);
+            sg = vi - nf;
+        }
+        const f32x4 xi = *reinterpret_cast<const f32x4*>(p.x + (size_t)vi * 4);
+        const f32x4 xj = *reinterpret_cast<const f32x4*>(p.x + (size_t)vj * 4);
+        const f32x4 yi = *reinterpret_cast<const f32x4*>(p.x0 + (size_t)vi * 4);
+        const f32x4 yj = *reinterpret_cast<const f32x4*>(p.x0 + (size_t)vj * 4);
+        const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
+        const float ex = yi[0] - yj[0], ey = yi[1] - yj[1], ez = yi[2] - yj[2];
+        d2 = dx * dx + dy * dy + dz * dz;
+        d02 = ex * ex + ey * ey + ez * ez;
+        if (EQUIV) {
+            const float inv = 1.0f / sqrtf(d2 + 1e-8f);
+            ux = dx * inv; uy = dy * inv; uz = dz * inv;
+        }
+        if (g == 0) {
+            float* dst = ri + (16 * wid + c) * 4;
+            dst[0] = __int_as_float(sg); dst[1] = ux; dst[2] = uy; dst[3] = uz;
+        }
+    }
+    const float* pa = p.pab + (size_t)vi * (2 * HP) + 8 * g;
+    const float* pb = p.pab + (size_t)vj * (2 * HP) + HP + 8 * g;
+    const float* wdp = p.wd + 8 * g;
+    const float* w0p = p.wd0 + 8 * g;
+
+    f32x4 acc[4][NS_T];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int i = 0; i < NS_T; ++i) acc[mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // B fragments: straight from global/L2 into a 2-deep REGISTER ring (each wave streams only the 7 column
+    // tiles it owns; per workgroup that is the same 363 KB of W2 an LDS stage would move, without the stage's
+    // one-block latency budget: an LDS-DMA issued at the top of a 450-cycle bf16 block has not landed when the
+    // next block starts, which is what bounds k_edge_lds_bf16).
+    const bf16x8* bsrc = reinterpret_cast<const bf16x8*>(p.Bp) + lane;
+    int btile[NS_T];
+#pragma unroll
+    for (int i = 0; i < NS_T; ++i) btile[i] = (wid + 4 * i < NT ? wid + 4 * i : NT - 1) * 64;
+    bf16x8 Bq[2][NS_T];
+    auto load_b = [&](bf16x8 (&dst)[NS_T], int kb) {
+        kb = kb < KB16 ? kb : KB16 - 1;
+#pragma unroll
+        for (int i = 0; i < NS_T; ++i) dst[i] = bsrc[(size_t)kb * NT * 64 + btile[i]];
+    };
+    auto load_a = [&](int kb, f32x4 (&v)[8]) {
+        kb = kb < KB16 ? kb : KB16 - 1;
+        v[0] = *reinterpret_cast<const f32x4*>(pa + 32 * kb);  v[1] = *reinterpret_cast<const f32x4*>(pa + 32 * kb + 4);
+        v[2] = *reinterpret_cast<const f32x4*>(pb + 32 * kb);  v[3] = *reinterpret_cast<const f32x4*>(pb + 32 * kb + 4);
+        v[4] = *reinterpret_cast<const f32x4*>(wdp + 32 * kb); v[5] = *reinterpret_cast<const f32x4*>(wdp + 32 * kb + 4);
+        v[6] = *reinterpret_cast<const f32x4*>(w0p + 32 * kb); v[7] = *reinterpret_cast<const f32x4*>(w0p + 32 * kb + 4);
+    };
+    auto agen = [&](const f32x4 (&v)[8]) -> bf16x8 {
+        f32x4 lo, hi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lo[j] = mcg_silu(fmaf(v[6][j], d02, fmaf(v[4][j], d2, v[0][j] + v[2][j])));
+            hi[j] = mcg_silu(fmaf(v[7][j], d02, fmaf(v[5][j], d2, v[1][j] + v[3][j])));
+        }
+        return mcg_pack_bf16(lo, hi);
+    };
+    // one k-block: [barrier] A-operand loads of block kb+1 | MFMAs of block kb | B loads of block kb+2 into the
+    // fragments just consumed | A operand of block kb+1 -> LDS.  sched_barrier pins this order (see mcg_gemm.h).
+    auto block = [&](bf16x8 (&Bc)[NS_T], int kb) {
+        const int buf = kb & 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // my A-tile write of the previous block
+        asm volatile("s_barrier" ::: "memory");                      // A(kb) visible; A ring half buf^1 free
+        f32x4 v[8];
+        load_a(kb + 1, v);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8* la = a_lds + buf * 4 * 64 + lane;
+        bf16x8 af[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) af[mt] = la[mt * 64];
+#pragma unroll
+        for (int i = 0; i < NS_T; ++i)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt][i] = mcg_mfma_bf16(af[mt], Bc[i], acc[mt][i]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(Bc, kb + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        a_lds[((buf ^ 1) * 4 + wid) * 64 + lane] = agen(v);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    load_b(Bq[0], 0);
+    load_b(Bq[1], 1);
+    {
+        f32x4 v[8];
+        load_a(0, v);
+        a_lds[(0 * 4 + wid) * 64 + lane] = agen(v);
+    }
+#pragma unroll 1
+    for (int kb = 0; kb < KB16; kb += 2) {        // KB16 = 14 is even
+        block(Bq[0], kb);
+        block(Bq[1], kb + 1);
+    }
+
+    // ---- epilogue
+    __syncthreads();       // (row facts `ri` were written before the first loop barrier; keeps the last block's reads apart)
+    float part[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[mt][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS_T; ++i) {
+        const int nt = wid + 4 * i;
+        if (nt >= NT) continue;
+        const float b2 = par[nt * 16 + c], wv = par[HP + nt * 16 + c];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float m = mcg_silu(acc[mt][i][r] + b2);
+                acc[mt][i][r] = m;
+                part[mt][r] = fmaf(wv, m, part[mt][r]);
+            }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = mcg_row16_sum(part[mt][r]);
+            if (c == 0) xchg[wid * 64 + 16 * mt + 4 * g + r] = v;
+        }
+    __syncthreads();
+    const int nseg = p.wave_poff[unit + 1] - p.wave_poff[unit];
+    const int pbase = p.wave_poff[unit];
+    float dot[4][4];
+    int rseg[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + 4 * g + r;
+            dot[mt][r] = ((xchg[row] + xchg[64 + row]) + xchg[128 + row]) + xchg[192 + row];
+            rseg[mt][r] = __float_as_int(ri[row * 4]);
+        }
+    if (EQUIV) {
+        if (wid != 0) return;
+        for (int s = 0; s < nseg; ++s) {
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (rseg[mt][r] == s) {
+                        const float* q = ri + (16 * mt + 4 * g + r) * 4;
+                        sx += q[1] * dot[mt][r]; sy += q[2] * dot[mt][r]; sz += q[3] * dot[mt][r];
+                    }
+            // each row is held by the 16 lanes of one lane group: divide the 16 identical copies out by summing
+            // over lane groups only (lanes with c == 0 carry the value)
+            sx = mcg_group4_sum(sx); sy = mcg_group4_sum(sy); sz = mcg_group4_sum(sz);
+            if (lane == 0) {
+                float* dst = p.P + (size_t)(pbase + s) * 4;
+                dst[0] = sx; dst[1] = sy; dst[2] = sz; dst[3] = 0.f;
+            }
+        }
+    } else {
+        float sel[4][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sel[mt][r] = rseg[mt][r] == c ? mcg_sigmoid(dot[mt][r] + p.bv) : 0.f;
+        const int row_seg = 4 * g;
+#pragma unroll
+        for (int i = 0; i < NS_T; ++i) {
+            const int nt = wid + 4 * i;
+            if (nt >= NT) continue;
+            f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) d = mcg_mfma(sel[mt][t], acc[mt][i][t], d);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (row_seg + r < nseg) p.P[(size_t)(pbase + row_seg + r) * HP + nt * 16 + c] = d[r];
+        }
+    }
+}
+
 // agg[v] = (sum of the per-wave partials that cover node v) / 100   (egnn.py:429-435)
 __global__ __launch_bounds__(128) void k_combine_agg(const float* __restrict__ P, const int* __restrict__ node_mol,
                                                       const int* __restrict__ node_off, const int* __restrict__ row_off,
@@ -1122,7 +1342,10 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
     if (bf16) {
         a.Bp = reinterpret_cast<const float*>(L.w2_Bp16);
         const int wgs = (pl->n_waves + 3) / 4;
-        if (pl->MT == 1) {
+        if (pl->MT == 4) {
+            if (equiv) hipLaunchKernelGGL((k_edge_bf16_w64<true>), dim3(pl->n_waves), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_edge_bf16_w64<false>), dim3(pl->n_waves), dim3(256), 0, s, a);
+        } else if (pl->MT == 1) {
             if (equiv) hipLaunchKernelGGL((k_edge_lds_bf16<1, true>), dim3(wgs), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((k_edge_lds_bf16<1, false>), dim3(wgs), dim3(256), 0, s, a);
         } else {
@@ -1132,6 +1355,7 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
         MCG_HIP(hipGetLastError());
         return MCG_OK;
     }
+    if (pl->MT == 4) { mcg_set_error("edge_mt = 4 plans are for the bf16 mode only"); return MCG_ERR_STATE; }
     // small batches: column-split latency variant (one workgroup per 16-row tile).  Measured per edge launch
     // (tools/bench_small.py): <= 256 tiles 24 us, <= 512 tiles 36 us vs 53 us for the throughput kernel's
     // single 16-row chain; beyond 512 tiles the 4x W2 staging traffic makes it slower (59 us at 527 tiles).
@@ -1303,7 +1527,7 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
     // SIMD cover each other's barrier / epilogue bubbles); measured faster than MT = 2 at configs 2 and 3.
     // MT = 2 stays selectable for experiments (MT = 3 needs 324 accumulators: hipcc spills it - removed).
     int best = 1;
-    if (edge_mt >= 1 && edge_mt <= 2) best = edge_mt;
+    if (edge_mt == 1 || edge_mt == 2 || edge_mt == 4) best = edge_mt;   // 4: 64-row units of the bf16 kernel
     if (const char* e = getenv("MCG_EDGE_MT")) { const int v = atoi(e); if (v >= 1 && v <= 2) best = v; }
     p->MT = best;
     p->n_waves = (p->n_mtiles + best - 1) / best;

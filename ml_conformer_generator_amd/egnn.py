@@ -120,10 +120,14 @@ class EGNNDynamics(torch.nn.Module):
             raise ValueError("compute_dtype must be 'f32' or 'bf16'")
         _lib.check(_lib.lib().mcg_egnn_set_precision(self.handle, 1 if compute_dtype == "bf16" else 0),
                    "mcg_egnn_set_precision")
+        if compute_dtype != self.compute_dtype:
+            self._plans.clear()          # tilings differ between the precisions
         self.compute_dtype = compute_dtype
 
     # -- plans --------------------------------------------------------------------
     def plan(self, n_nodes: torch.Tensor, max_n_nodes: int, edge_mt: int = 0) -> BatchPlan:
+        if edge_mt == 0 and self.compute_dtype == "bf16" and int(n_nodes.min()) >= 6:
+            edge_mt = 4          # bf16: 64-row workgroup tiles (needs <= 16 nodes per 64 edge rows)
         key = (int(max_n_nodes), int(edge_mt), tuple(int(v) for v in n_nodes.reshape(-1).tolist()))
         p = self._plans.get(key)
         if p is None:

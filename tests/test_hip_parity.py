@@ -453,7 +453,10 @@ def test_bf16_mode_vs_emulation_and_fp32(edm_sd):
     ctx = torch.randn(4, 1, 3).repeat(1, N, 1) * nm
     t = torch.full((4, 1), 0.4)
     out = d(t.to(DEV), z.to(DEV), nm.to(DEV), em.to(DEV), ctx.to(DEV)).cpu()
+    assert next(iter(d._plans.values())).edge_mt == 4                  # 64-row-tile bf16 kernel
+    out_mt1 = d.run(d.plan(sizes, N, edge_mt=1), t.reshape(-1).to(DEV), z.to(DEV), ctx.to(DEV)).cpu()   # 16-row-tile kernel
     emu = _egnn_dynamics_bf16_emulated(edm_sd, t, z, nm, em, ctx)
+    assert float((out_mt1 - emu).abs().max()) / float(emu.abs().max()) < 3e-3
     ref = EO.egnn_dynamics(edm_sd, t, z, nm, em, ctx)
     sc = float(ref.abs().max())
     e_emu = float((out - emu).abs().max()) / sc
