@@ -257,7 +257,9 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"configs[1]: n_samples={B}/GPU, {args.n_atoms}"
                                    f"{'+-' + str(args.variance) if args.variance else ''} heavy atoms, "
-                                   f"diffusion_steps={args.diffusion_steps}, fp32 HIP EGNN + GCN",
+                                   f"diffusion_steps={args.diffusion_steps}, "
+                                   + ("fp32 HIP EGNN + GCN" if args.dtype == "f32" else
+                                      "bf16-operand MFMA HIP EGNN (fp32 accumulate/state) + fp32 GCN"),
                        "parallelism": f"batch-sharded x{world}, RCCL all_gather at end" if world > 1 else "single GPU",
                        "edge_rows_per_wave": 16 * plan.edge_mt, "real_edges": plan.n_real_edges,
                        "real_nodes": plan.n_real_nodes},

@@ -10,7 +10,8 @@ import os
 from typing import Dict, List, Sequence
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmlconfgen_hip.so")
+# MCG_LIB_PATH: measurement builds only (tools/build_variants.sh: ablation / experiment variants of the same library)
+LIB_PATH = os.environ.get("MCG_LIB_PATH") or os.path.join(_HERE, "libmlconfgen_hip.so")
 
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 _pp = C.POINTER(C.c_void_p)

@@ -383,8 +383,11 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
     }
 
     constexpr int NG = H / 16;      // 26 full groups, then one tail k-step (k = 416 + g)
+#if MCG_PRIO == 4
+    __builtin_amdgcn_s_setprio(3);
+#endif
 #pragma unroll 1
-    for (int q = 0; q < NG; ++q) {
+    for (int q = 0; q < ((MCG_ABLATE & 16) ? 1 : NG); ++q) {
         const int buf = q & 1;
 #if !(MCG_ABLATE & 4)
         // ONE barrier per group.  The DMA of group q was issued a whole group (~3.5k cycles of MFMA
@@ -466,6 +469,9 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
             for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mcg_mfma(a4[mt][0], b, acc[mt][nt]);
         }
     }
+#if MCG_PRIO == 4
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #if (MCG_ABLATE & 1)
     {
         float sink = 0.f;
@@ -479,6 +485,11 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
     edge_epilogue<MT, EQUIV>(p, wave, live, lane, acc, R, lds + 2 * GROUP_LDS_FLOATS, lds + 2 * GROUP_LDS_FLOATS + HP);
 #endif
 }
+
+// (A 12-k-group variant of this kernel - 35 groups, no tail step, 51 KiB of LDS, THREE workgroups per CU - was
+//  built and measured: 165 / 612 us per launch at configs 2 / 3 against 157 / 579 us for this one.  A third
+//  resident wave buys nothing here because fp32 MFMA and VALU work do not overlap on gfx950 - see DESIGN.md,
+//  "what bounds the edge kernel" - while the extra barriers and the in-place A-operand generation cost.)
 
 // ---- v3: latency variant for SMALL batches - the 4 waves of a workgroup split the 27 column tiles of ONE
 // 16-row edge tile (7,7,7,6).  With fewer than ~1000 tiles in the batch the throughput kernel above leaves
@@ -1320,9 +1331,9 @@ template <int MT>
 void launch_edge(bool equiv, const EdgeArgs& a, int n_waves, hipStream_t s) {
     if (g_edge_variant < 0) {
         const char* e = getenv("MCG_EDGE_KERNEL");
-        g_edge_variant = (e && atoi(e) == 0) ? 0 : 1;
+        g_edge_variant = e ? atoi(e) : 1;
     }
-    if (g_edge_variant == 1) {
+    if (g_edge_variant >= 1) {
         const int wgs = (n_waves + 3) / 4;
         if (equiv) hipLaunchKernelGGL((k_edge_lds<MT, true>), dim3(wgs), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_edge_lds<MT, false>), dim3(wgs), dim3(256), 0, s, a);
