@@ -75,6 +75,7 @@ struct EdgeArgs {
     float bv;               // attention bias (GCL)
     const int* n_nodes; const int* node_off; const int* row_off; int B;
     const int* tile_mol;    // molecule of the first row of every 16-row tile
+    const int2* row_ij;     // [n_mtiles*16] compact node ids (i, j) of every edge row, (-1,-1) on the padded tail
     const int* wave_nf;     // first compact node touched by each wave
     const int* wave_poff;   // prefix offsets of (wave, node) partial slots
     int n_rows; int n_mtiles; int n_waves;
@@ -94,18 +95,12 @@ __device__ __forceinline__ void edge_decode(const EdgeArgs& p, int wave, bool li
     for (int mt = 0; mt < MT; ++mt) {
         const int tile = wave * MT + mt;
         const int r = tile * 16 + c;
+        // one 8-byte load instead of the tile -> molecule -> (row_off, n, node_off) -> division chain: the row
+        // decode sits at the head of every workgroup's dependent-load chain and nothing overlaps it
         int vi = 0, vj = 0, sg = -1;
-        if (live && tile < p.n_mtiles && r < p.n_rows) {
-            int b = p.tile_mol[tile];
-            while (r >= p.row_off[b + 1]) ++b;
-            const int n = p.n_nodes[b];
-            const int local = r - p.row_off[b];
-            const int i = local / (n - 1);
-            const int jj = local - i * (n - 1);
-            const int j = jj + (jj >= i ? 1 : 0);
-            vi = p.node_off[b] + i;
-            vj = p.node_off[b] + j;
-            sg = vi - nf;
+        if (live && tile < p.n_mtiles) {
+            const int2 ij = p.row_ij[r];
+            if (ij.x >= 0) { vi = ij.x; vj = ij.y; sg = vi - nf; }
         }
         R.ni[mt] = vi; R.nj[mt] = vj; R.seg[mt] = sg;
         const f32x4 xi = *reinterpret_cast<const f32x4*>(p.x + (size_t)vi * 4);
@@ -303,11 +298,6 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
     // two staging buffers + the epilogue's per-column parameters (b2 | wv): ONE array on purpose -
     // a second __shared__ object makes hipcc drain vmcnt(0) before the staged ds_reads
     __shared__ __attribute__((aligned(16))) float lds[2 * GROUP_LDS_FLOATS + 2 * HP];
-    for (int i = threadIdx.x; i < HP; i += 256) {
-        lds[2 * GROUP_LDS_FLOATS + i] = p.b2[i];
-        lds[2 * GROUP_LDS_FLOATS + HP + i] = p.wv[i];
-    }
-    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
@@ -369,6 +359,13 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
 
     // prologue: B group 0 in flight, A operand of group 0 generated
     stage(0, 0);
+    // epilogue parameters -> LDS.  Issued behind the row decode and the first staging DMA (not in front of
+    // them with a __syncthreads: that put one more memory round trip at the head of every workgroup); they are
+    // read only after the main loop, whose first barrier (vmcnt(0) + lgkmcnt(0)) publishes them.
+    for (int i = threadIdx.x; i < HP; i += 256) {
+        lds[2 * GROUP_LDS_FLOATS + i] = p.b2[i];
+        lds[2 * GROUP_LDS_FLOATS + HP + i] = p.wv[i];
+    }
     f32x4 a4[MT];
     {
         f32x4 va[MT], vb[MT];
@@ -394,7 +391,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
         // work) ago and this wave's mid-loop operand wait has drained the vector-memory queue since,
         // so "my pieces of group q have landed" is already true here; after the barrier it is true
         // for every wave, and every wave has also finished reading buffer buf^1 (group q-1).
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
 #endif
         // A-operand inputs of the NEXT group (or of the tail step) - ordinary loads, issued first
@@ -843,16 +840,9 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
     {
         const int tile = unit * 4 + wid;
         const int r = tile * 16 + c;
-        if (tile < p.n_mtiles && r < p.n_rows) {
-            int b = p.tile_mol[tile];
-            while (r >= p.row_off[b + 1]) ++b;
-            const int n = p.n_nodes[b];
-            const int local = r - p.row_off[b];
-            const int i = local / (n - 1);
-            const int jj = local - i * (n - 1);
-            vi = p.node_off[b] + i;
-            vj = p.node_off[b] + jj + (jj >= i ? 1 : 0);
-            sg = vi - nf;
+        if (tile < p.n_mtiles) {
+            const int2 ij = p.row_ij[r];
+            if (ij.x >= 0) { vi = ij.x; vj = ij.y; sg = vi - nf; }
         }
         const f32x4 xi = *reinterpret_cast<const f32x4*>(p.x + (size_t)vi * 4);
         const f32x4 xj = *reinterpret_cast<const f32x4*>(p.x + (size_t)vj * 4);
@@ -1215,6 +1205,7 @@ struct mcg_egnn {
 
 struct mcg_plan {
     int B = 0, N = 0, M = 0, n_rows = 0, n_mtiles = 0, MT = 1, n_waves = 0, n_pslots = 0;
+    int2* row_ij = nullptr;
     int *n_nodes = nullptr, *node_off = nullptr, *row_off = nullptr, *tile_mol = nullptr, *wave_nf = nullptr,
         *wave_poff = nullptr, *node_mol = nullptr, *node_slots = nullptr;   // node_slots: [M][8] or null
     float *x = nullptr, *x0 = nullptr, *h = nullptr, *h2 = nullptr, *pab = nullptr, *agg = nullptr, *t1 = nullptr,
@@ -1348,7 +1339,7 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
     EdgeArgs a;
     a.pab = pl->pab; a.x = pl->x; a.x0 = pl->x0; a.wd = L.wd; a.wd0 = L.wd0; a.Bp = L.w2_Bp; a.b2 = L.b2;
     a.wv = L.wv; a.bv = L.bv; a.n_nodes = pl->n_nodes; a.node_off = pl->node_off; a.row_off = pl->row_off;
-    a.B = pl->B; a.tile_mol = pl->tile_mol; a.wave_nf = pl->wave_nf; a.wave_poff = pl->wave_poff;
+    a.B = pl->B; a.tile_mol = pl->tile_mol; a.row_ij = pl->row_ij; a.wave_nf = pl->wave_nf; a.wave_poff = pl->wave_poff;
     a.n_rows = pl->n_rows; a.n_mtiles = pl->n_mtiles; a.n_waves = pl->n_waves; a.P = P;
     if (bf16) {
         a.Bp = reinterpret_cast<const float*>(L.w2_Bp16);
@@ -1582,6 +1573,22 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
         }
     }
     int e = 0;
+    {   // (i, j) of every edge row, padded to whole tiles
+        std::vector<int> ij((size_t)(p->n_mtiles > 0 ? p->n_mtiles : 1) * 32, -1);
+        for (int b = 0; b < B; ++b) {
+            const int n = nn[b];
+            for (int i = 0; i < n && n > 1; ++i)
+                for (int jj = 0; jj < n - 1; ++jj) {
+                    const size_t r = (size_t)row_off[b] + (size_t)i * (n - 1) + jj;
+                    ij[2 * r] = node_off[b] + i;
+                    ij[2 * r + 1] = node_off[b] + jj + (jj >= i ? 1 : 0);
+                }
+        }
+        int* d = nullptr;
+        e |= upload_i(ij, &d);
+        p->row_ij = reinterpret_cast<int2*>(d);
+        p->allocs.push_back(d);
+    }
     if (slots_ok && p->M > 0) {
         e |= upload_i(node_slots, &p->node_slots);
         p->allocs.push_back(p->node_slots);
