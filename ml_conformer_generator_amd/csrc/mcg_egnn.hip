@@ -186,22 +186,34 @@ __device__ __forceinline__ void edge_epilogue(const EdgeArgs& p, int wave, bool 
         // C/D register acc[.][nt][t] this lane already holds, and the A operand is built from the row facts
         // it already holds (seg index = lane & 15).  4 MFMAs per column tile replace a per-segment loop of
         // masked FMAs + cross-lane shuffles, for any number of segments up to 16 per tile.
+        const int sc = (c >> 2) + 4 * (c & 3);         // segment whose sum lands in D row c
         float sel[MT][4];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sel[mt][r] = rseg[mt][r] == c ? scale[mt][r] : 0.f;   // m * att * edge_mask
-        const int row_seg = 4 * g;                     // D rows held by this lane: segments 4g .. 4g+3
+            for (int r = 0; r < 4; ++r) sel[mt][r] = rseg[mt][r] == sc ? scale[mt][r] : 0.f;   // m * att * edge_mask
+        // (segment s sits in D row 4*(s%4) + s/4, i.e. register s/4 of lane group s%4: with the usual <= 4
+        //  segments per tile every lane group stores one useful row per column tile and registers 1..3 are
+        //  skipped by a wave-uniform test, instead of lane group 0 issuing four quarter-filled stores)
+        // three column tiles at a time: the 4*MT MFMAs of one tile form a dependent chain (~60 cycles per link
+        // instead of 32 when issued back to back), three interleaved chains keep the pipe busy
+        static_assert(NT % 3 == 0, "column tiles are processed in threes");
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nt0 = 0; nt0 < NT; nt0 += 3) {
+            f32x4 d[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) d[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) d = mcg_mfma(sel[mt][t], acc[mt][nt][t], d);
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (row_seg + r < nseg) p.P[(size_t)(pbase + row_seg + r) * HP + nt * 16 + c] = d[r];
+                    for (int j = 0; j < 3; ++j) d[j] = mcg_mfma(sel[mt][t], acc[mt][nt0 + j][t], d[j]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * r < nseg && g + 4 * r < nseg) p.P[(size_t)(pbase + g + 4 * r) * HP + (nt0 + j) * 16 + c] = d[j][r];
         }
     }
 }
@@ -640,8 +652,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_ns(EdgeArgs p) {
     } else {
         float sel[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sel[r] = rseg[r] == c ? mcg_sigmoid(dot[r] + p.bv) : 0.f;
-        const int row_seg = 4 * g;
+        for (int r = 0; r < 4; ++r) sel[r] = rseg[r] == (c >> 2) + 4 * (c & 3) ? mcg_sigmoid(dot[r] + p.bv) : 0.f;
 #pragma unroll
         for (int i = 0; i < NS_T; ++i) {
             const int nt = wid + 4 * i;
@@ -651,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_ns(EdgeArgs p) {
             for (int t = 0; t < 4; ++t) d = mcg_mfma(sel[t], acc[i][t], d);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (row_seg + r < nseg) p.P[(size_t)(pbase + row_seg + r) * HP + nt * 16 + c] = d[r];
+                if (4 * r < nseg && g + 4 * r < nseg) p.P[(size_t)(pbase + g + 4 * r) * HP + nt * 16 + c] = d[r];
         }
     }
 }
@@ -1005,20 +1016,24 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sel[mt][r] = rseg[mt][r] == c ? mcg_sigmoid(dot[mt][r] + p.bv) : 0.f;
-        const int row_seg = 4 * g;
+            for (int r = 0; r < 4; ++r) sel[mt][r] = rseg[mt][r] == (c >> 2) + 4 * (c & 3) ? mcg_sigmoid(dot[mt][r] + p.bv) : 0.f;
+        // the 16 MFMAs of one column tile are a dependent chain: run the wave's 7 chains interleaved
+        f32x4 d[NS_T];
+#pragma unroll
+        for (int i = 0; i < NS_T; ++i) d[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < NS_T; ++i) d[i] = mcg_mfma(sel[mt][t], acc[mt][i][t], d[i]);
 #pragma unroll
         for (int i = 0; i < NS_T; ++i) {
             const int nt = wid + 4 * i;
             if (nt >= NT) continue;
-            f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) d = mcg_mfma(sel[mt][t], acc[mt][i][t], d);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (row_seg + r < nseg) p.P[(size_t)(pbase + row_seg + r) * HP + nt * 16 + c] = d[r];
+                if (4 * r < nseg && g + 4 * r < nseg) p.P[(size_t)(pbase + g + 4 * r) * HP + nt * 16 + c] = d[i][r];
         }
     }
 }
