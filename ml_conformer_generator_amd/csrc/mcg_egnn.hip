@@ -1240,6 +1240,11 @@ struct mcg_plan {
     hipGraphExec_t graph_exec = nullptr;
     const void* g_key[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // xh, context, out, model, bf16
     int graph_failed = 0;
+    // Callers whose tensors move between calls (the reference's own sampler loop allocates a fresh xh / out
+    // every step) would force a re-capture per call: after the second key change the graph is captured on
+    // plan-owned staging buffers instead and each call adds three small device-to-device copies around it.
+    int key_changes = 0;
+    float *xh_stage = nullptr, *ctx_stage = nullptr, *out_stage = nullptr;
     int latency_mode = -1;                  // column-split edge kernel: -1 auto (small batches), 0 never, 1 always
 };
 
@@ -1732,10 +1737,32 @@ int mcg_egnn_dynamics(const mcg_egnn* m, mcg_plan* pl, const float* t, const flo
     if (!use_graph || pl->graph_failed || !pl->t_buf || !pl->cap_stream) return dynamics_launch(m, pl, t, xh, context, out, s);
     // t is the only argument that moves between calls of a sampling run: stage it, replay the graph
     MCG_HIP(hipMemcpyAsync(pl->t_buf, t, (size_t)pl->B * sizeof(float), hipMemcpyDeviceToDevice, s));
+    const size_t n_xh = (size_t)pl->B * pl->N * 11, n_ctx = (size_t)pl->B * pl->N * 3;
+    float* const out_user = out;
+    if (pl->xh_stage) {          // staged mode
+        MCG_HIP(hipMemcpyAsync(pl->xh_stage, xh, n_xh * sizeof(float), hipMemcpyDeviceToDevice, s));
+        MCG_HIP(hipMemcpyAsync(pl->ctx_stage, context, n_ctx * sizeof(float), hipMemcpyDeviceToDevice, s));
+        xh = pl->xh_stage; context = pl->ctx_stage; out = pl->out_stage;
+    }
+    auto finish = [&]() -> int {
+        if (out != out_user) MCG_HIP(hipMemcpyAsync(out_user, out, n_xh * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return MCG_OK;
+    };
     const void* key[5] = {xh, context, out, m, m->bf16 ? (const void*)1 : nullptr};
     if (pl->graph_exec && memcmp(key, pl->g_key, sizeof(key)) == 0) {
         MCG_HIP(hipGraphLaunch(pl->graph_exec, s));
-        return MCG_OK;
+        return finish();
+    }
+    if (pl->graph_exec && !pl->xh_stage && (key[0] != pl->g_key[0] || key[1] != pl->g_key[1] || key[2] != pl->g_key[2]) &&
+        ++pl->key_changes >= 2) {
+        float* st = nullptr;
+        if (hipMalloc((void**)&st, (2 * n_xh + n_ctx + 16) * sizeof(float)) == hipSuccess) {
+            pl->allocs.push_back(st);
+            pl->xh_stage = st; pl->out_stage = st + n_xh; pl->ctx_stage = st + 2 * n_xh;
+            if (getenv("MCG_VERBOSE")) fprintf(stderr, "[mcg] caller tensors move between calls: graph on staging buffers\n");
+            return mcg_egnn_dynamics(m, pl, t, xh, context, out, stream);
+        }
+        (void)hipGetLastError();
     }
     if (pl->graph_exec) { (void)hipGraphExecDestroy(pl->graph_exec); pl->graph_exec = nullptr; }
     hipGraph_t graph = nullptr;
@@ -1743,7 +1770,8 @@ int mcg_egnn_dynamics(const mcg_egnn* m, mcg_plan* pl, const float* t, const flo
         (void)hipGetLastError();
         pl->graph_failed = 1;
         if (getenv("MCG_VERBOSE")) fprintf(stderr, "[mcg] hipStreamBeginCapture failed: plain launches\n");
-        return dynamics_launch(m, pl, t, xh, context, out, s);
+        if (int e = dynamics_launch(m, pl, t, xh, context, out, s)) return e;
+        return finish();
     }
     const int rc = dynamics_launch(m, pl, pl->t_buf, xh, context, out, pl->cap_stream);
     const hipError_t ce = hipStreamEndCapture(pl->cap_stream, &graph);
@@ -1754,13 +1782,14 @@ int mcg_egnn_dynamics(const mcg_egnn* m, mcg_plan* pl, const float* t, const flo
         pl->graph_exec = nullptr;
         pl->graph_failed = 1;                  // fall back to plain launches for this plan
         if (getenv("MCG_VERBOSE")) fprintf(stderr, "[mcg] graph capture failed (rc=%d, end=%d): plain launches\n", rc, (int)ce);
-        return dynamics_launch(m, pl, t, xh, context, out, s);
+        if (int e = dynamics_launch(m, pl, t, xh, context, out, s)) return e;
+        return finish();
     }
     (void)hipGraphDestroy(graph);
     if (getenv("MCG_VERBOSE")) fprintf(stderr, "[mcg] denoiser call captured as a HIP graph (B=%d)\n", pl->B);
     memcpy(pl->g_key, key, sizeof(key));
     MCG_HIP(hipGraphLaunch(pl->graph_exec, s));
-    return MCG_OK;
+    return finish();
 }
 
 // Measurement hook: launch the edge kernel of one layer `iters` times back-to-back on the plan's

@@ -602,3 +602,60 @@ def test_shape_tanimoto_kernel_vs_golden_and_oracle():
         ob, ow = SO.best_orientation_score(ref, many[b, : int(nn[b])])
         assert abs(float(bst[b]) - ob) < 2e-4
     assert abs(tanimoto_score(g["xyz_yibfeu"], g["xyz_paba"]) - float(g["yibfeu__paba"][0])) < 2e-4
+
+
+def test_integration_md_ctypes_stub_runs_as_documented(edm_sd, gcn_sd):
+    """Executes the reference-side binding printed in INTEGRATION.md section 3 verbatim (only the library
+    path is made absolute) around stand-ins that expose what the reference's modules expose
+    (`.egnn.state_dict()`, `.state_dict()`), with FRESH tensors on every call as the reference's sampler loop
+    produces them - which also drives the plan's staged-graph mode - and checks both seams against the oracle."""
+    import re
+    from ml_conformer_generator_amd import _lib
+    from oracle import egnn_oracle as EO
+    from oracle import gcn_oracle as GO
+    from oracle import host_oracle as HO
+    from ml_conformer_generator_amd.synthetic import synth_gcn_inputs
+    import os
+    md = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", md, flags=re.S)
+    stub = next(b for b in blocks if "class HipEGNNDynamics" in b)
+    stub = stub.replace('C.CDLL("libmlconfgen_hip.so")', f'C.CDLL({_lib.LIB_PATH!r})')
+    ns = {}
+    exec(compile(stub, "INTEGRATION.md#3", "exec"), ns)
+
+    class _Egnn:
+        def state_dict(self):
+            return {k[len("dynamics.egnn."):]: v for k, v in edm_sd.items() if k.startswith("dynamics.egnn.")}
+
+    class _RefDynamics:
+        egnn = _Egnn()
+
+    dyn = ns["HipEGNNDynamics"](_RefDynamics())
+    sizes = torch.tensor([17, 15, 19, 16])
+    N = 19
+    nm, em = HO.masks_from_sizes(sizes, N)
+    ctx = torch.tensor([-0.9, -1.6, -1.7]).view(1, 1, 3).repeat(4, N, 1) * nm
+    for it in range(4):                     # new xh / t / out tensors every call
+        torch.manual_seed(100 + it)
+        xh = torch.randn(4, N, 11) * nm
+        t = torch.full((4, 1), 0.1 + 0.2 * it)
+        keep = [torch.empty(1000 + 64 * it, device=DEV)]       # shifts the caching allocator's addresses
+        out = dyn(t.to(DEV), xh.to(DEV), nm.to(DEV), em.to(DEV), ctx.clone().to(DEV)).cpu()
+        ref = EO.egnn_dynamics(edm_sd, t, xh, nm, em, ctx)
+        ok, err, sc = close(out, ref)
+        assert ok, (it, err, sc)
+        del keep
+
+    class _RefSeer:
+        device, dimension = DEV, 42
+
+        def state_dict(self):
+            return gcn_sd
+
+    seer = ns["HipAdjMatSeer"](_RefSeer())
+    el, dm, am = synth_gcn_inputs(3, [17, 27, 39], seed=5)
+    logits = seer(el.to(DEV), dm.to(DEV), am.to(DEV)).cpu()
+    ref = GO.adj_mat_seer(gcn_sd, el, dm, am)
+    ok, err, sc = close(logits, ref)
+    assert ok, (err, sc)
+    assert torch.equal(logits.argmax(-1), ref.argmax(-1))
