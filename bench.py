@@ -250,12 +250,18 @@ def main():
                 traffic = pmc[key]["traffic_bytes_corrected"]
         except Exception:  # noqa: BLE001
             pass
+        if B == 64 and args.variance == 0 and args.n_atoms == 27:
+            cfg_label = "configs[1]"
+        elif B == 256 and args.variance == 12 and args.n_atoms == 27:
+            cfg_label = "configs[2] shape" if world == 1 else "configs[3] shape (256/GPU)"
+        else:
+            cfg_label = "custom"
         out = {
             "metric": "valid molecules/sec @100 diffusion steps",
             "value": value, "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"configs[1]: n_samples={B}/GPU, {args.n_atoms}"
+            "config": {"workload": f"{cfg_label}: n_samples={B}/GPU, {args.n_atoms}"
                                    f"{'+-' + str(args.variance) if args.variance else ''} heavy atoms, "
                                    f"diffusion_steps={args.diffusion_steps}, "
                                    + ("fp32 HIP EGNN + GCN" if args.dtype == "f32" else
