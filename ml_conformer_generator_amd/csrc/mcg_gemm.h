@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void mcg_gemm_bf16_kernel(McgGemmArgs p) {
     }
 }
 
-template <int RN>
+template <int RN, int RING = 3>
 __global__ __launch_bounds__(256) void mcg_gemm_kernel(McgGemmArgs p) {
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void mcg_gemm_kernel(McgGemmArgs p) {
         // 3-deep register ring: the loads of group q+3 are issued right after group q's MFMAs
         // and are consumed two compute blocks (>= 1k cycles of MFMA work) later - there is
         // less than one wave per SIMD on the small node GEMMs, so latency is hidden by ILP.
-        f32x4 Ar[3][2], Br[3][RN];
+        f32x4 Ar[RING][2], Br[RING][RN];
         // loads are UNCONDITIONAL (group index and column tile clamped): a runtime "load or zero"
         // select makes hipcc branch around every load and drain vmcnt(0) behind it.
         auto load_group = [&](int slot, int q) {
@@ -272,20 +272,23 @@ __global__ __launch_bounds__(256) void mcg_gemm_kernel(McgGemmArgs p) {
 #pragma unroll
                     for (int n = 0; n < RN; ++n) acc[m][n] = mcg_mfma(Ar[slot][m][s], Br[slot][n][s], acc[m][n]);
         };
-        load_group(0, 0); load_group(1, 1); load_group(2, 2);
+#pragma unroll
+        for (int i = 0; i < RING; ++i) load_group(i, i);
         // branch-free body (control flow inside the loop makes hipcc's wait-count pass fall back to
-        // vmcnt(0) at the loop head, draining the ring); the <= 2 leftover groups are peeled.
+        // vmcnt(0) at the loop head, draining the ring); the <= RING-1 leftover groups are peeled.
         int q = 0;
 #pragma unroll 1
-        for (; q + 3 <= groups; q += 3) {
-            // sched_barrier pins "MFMAs of group q | loads of group q+3": left alone, hipcc clusters all
-            // 15 loads at the loop bottom and the first MFMA block then waits for every one of them.
-            compute(0); __builtin_amdgcn_sched_barrier(0); load_group(0, q + 3); __builtin_amdgcn_sched_barrier(0);
-            compute(1); __builtin_amdgcn_sched_barrier(0); load_group(1, q + 4); __builtin_amdgcn_sched_barrier(0);
-            compute(2); __builtin_amdgcn_sched_barrier(0); load_group(2, q + 5); __builtin_amdgcn_sched_barrier(0);
+        for (; q + RING <= groups; q += RING) {
+            // sched_barrier pins "MFMAs of group q | loads of group q+RING": left alone, hipcc clusters all
+            // the loads at the loop bottom and the first MFMA block then waits for every one of them.
+#pragma unroll
+            for (int i = 0; i < RING; ++i) {
+                compute(i); __builtin_amdgcn_sched_barrier(0); load_group(i, q + RING + i); __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (q < groups) compute(0);
-        if (q + 1 < groups) compute(1);
+#pragma unroll
+        for (int i = 0; i < RING - 1; ++i)
+            if (q + i < groups) compute(i);
         }
     tail_steps:
         const int tail = (K - groups * 16) / 4;

@@ -1,0 +1,74 @@
+// Measurement tool: the three node-GEMM shapes of one GCL layer (mcg_gemm.h), timed the way the denoiser
+// runs them - a different weight set every launch (63 sets per call: L2-cold, Infinity-Cache-warm) and the
+// A operand freshly written by the previous launch.   ./gemm_bench [M]
+#include "../../ml_conformer_generator_amd/csrc/mcg_gemm.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#ifndef RINGS
+#define RINGS 3
+#endif
+template <int RN, int RING>
+static void launch(const McgGemmArgs& a, hipStream_t s) {
+    const int rowblocks = (a.M + 31) / 32;
+    const long wave_cols = (a.n_tiles + RN - 1) / RN;
+    const long waves = (long)rowblocks * wave_cols;
+    hipLaunchKernelGGL((mcg_gemm_kernel<RN, RING>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+
+}
+
+int main(int argc, char** argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 1728;
+    const int H = 420, HP = 432, NT = 27, SETS = 32;
+    float *h, *agg, *t1, *h2, *pab;
+    hipMalloc(&h, (size_t)M * HP * 4 + 256); hipMalloc(&agg, (size_t)M * HP * 4 + 256); hipMalloc(&t1, (size_t)M * HP * 4 + 256);
+    hipMalloc(&h2, (size_t)M * HP * 4 + 256); hipMalloc(&pab, (size_t)M * 2 * HP * 4 + 256);
+    std::vector<float> init((size_t)M * HP);
+    for (size_t i = 0; i < init.size(); ++i) init[i] = 0.01f * (float)((i * 2654435761u) % 200) - 1.f;
+    hipMemcpy(h, init.data(), init.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(agg, init.data(), init.size() * 4, hipMemcpyHostToDevice);
+    const size_t n_pab = mcg_pack4_floats(H, 2 * NT), n_w3 = 2 * mcg_pack4_floats(H, NT), n_w4 = mcg_pack4_floats(H, NT);
+    float *Wpab, *W3, *W4, *bias;
+    hipMalloc(&Wpab, SETS * n_pab * 4); hipMalloc(&W3, SETS * n_w3 * 4); hipMalloc(&W4, SETS * n_w4 * 4); hipMalloc(&bias, 2 * HP * 4);
+    std::vector<float> w(n_pab);
+    for (size_t i = 0; i < w.size(); ++i) w[i] = 0.001f * (float)((i * 40503u) % 97) - 0.05f;
+    for (int k = 0; k < SETS; ++k) {
+        hipMemcpy(Wpab + k * n_pab, w.data(), n_pab * 4, hipMemcpyHostToDevice);
+        hipMemcpy(W3 + k * n_w3, w.data(), n_w3 * 4, hipMemcpyHostToDevice);
+        hipMemcpy(W4 + k * n_w4, w.data(), n_w4 * 4, hipMemcpyHostToDevice);
+    }
+    hipMemset(bias, 0, 2 * HP * 4);
+    hipStream_t s; hipStreamCreate(&s);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto args = [&](int which, int set) {
+        McgGemmArgs g{};
+        g.bias = bias; g.M = M; g.act = MCG_ACT_NONE;
+        if (which == 0) { g.A1 = h; g.lda1 = HP; g.K1 = H; g.Bp = Wpab + set * n_pab; g.C = pab; g.ldc = 2 * HP; g.n_tiles = 2 * NT; g.n_store = 2 * HP; }
+        if (which == 1) { g.A1 = h; g.lda1 = HP; g.K1 = H; g.A2 = agg; g.lda2 = HP; g.K2 = H; g.Bp = W3 + set * n_w3; g.C = t1; g.ldc = HP; g.n_tiles = NT; g.n_store = HP; g.act = MCG_ACT_SILU; }
+        if (which == 2) { g.A1 = t1; g.lda1 = HP; g.K1 = H; g.Bp = W4 + set * n_w4; g.resid = h; g.ldr = HP; g.C = h2; g.ldc = HP; g.n_tiles = NT; g.n_store = HP; }
+        return g;
+    };
+    const char* names[3] = {"Pab  K=420 N=864", "W3   K=840 N=432 +SiLU", "W4   K=420 N=432 +resid"};
+    const double flops[3] = {2.0 * M * H * 864, 2.0 * M * 2 * H * 432, 2.0 * M * H * 432};
+    const int iters = 20 * SETS;
+    for (int which = 0; which < 3; ++which) {
+        for (int rn = 1; rn <= 3; ++rn) {
+            auto run = [&](int n) {
+                for (int i = 0; i < n; ++i) {
+                    const McgGemmArgs g = args(which, i % SETS);
+                    if (rn == 1) launch<1, RINGS>(g, s); else if (rn == 2) launch<2, RINGS>(g, s); else launch<3, RINGS>(g, s);
+                }
+            };
+            run(SETS);
+            hipStreamSynchronize(s);
+            hipEventRecord(e0, s);
+            run(iters);
+            hipEventRecord(e1, s);
+            hipStreamSynchronize(s);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("M=%d ring=%d %-26s RN=%d  %.1f us  %.1f TFLOP/s\n", M, RINGS, names[which], rn, ms * 1e3 / iters, flops[which] / (ms * 1e-3 / iters) / 1e12);
+        }
+    }
+    return 0;
+}
