@@ -20,6 +20,14 @@
 
 enum { MCG_ACT_NONE = 0, MCG_ACT_SILU = 1, MCG_ACT_RELU = 2 };
 
+// XCD-aware workgroup order: block b runs on XCD b % 8 (observed; speed only).  With the linear (row block,
+// wave column) numbering a contiguous block range is a band of rows x all columns, so after the remap every
+// XCD reads 1/8 of A and all of B into its L2 instead of nearly all of both (config 2 Pab GEMM: 35 MB -> 14.5 MB
+// of fabric traffic per launch).
+#ifndef MCG_GEMM_BLOCK
+#define MCG_GEMM_BLOCK(b, n) mcg_xcd_remap((b), (n))
+#endif
+
 struct McgGemmArgs {
     const float* A1; int lda1; int K1;      // first K segment  (K1 % 4 == 0)
     const float* A2; int lda2; int K2;      // optional second segment (concat along K), K2 may be 0
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(256) void mcg_gemm_bf16_kernel(McgGemmArgs p) {
     const int wid = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int wave_cols = (p.n_tiles + RN - 1) / RN;
-    const int wlin = blockIdx.x * 4 + wid;
+    const int wlin = MCG_GEMM_BLOCK(blockIdx.x, gridDim.x) * 4 + wid;
     if (wlin >= ((p.M + 31) / 32) * wave_cols) return;
     const int row0 = (wlin / wave_cols) * 32;
     const int nt0 = (wlin % wave_cols) * RN;
@@ -104,20 +112,23 @@ __global__ __launch_bounds__(256) void mcg_gemm_bf16_kernel(McgGemmArgs p) {
 #pragma unroll
         for (int n = 0; n < RN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // epilogue operands (bias, residual) are fetched NOW so their latency hides under the K loop
-    float ebias[RN];
-    float eres[2][RN][4];
+    // Accumulators are kept TRANSPOSED (weights as the MFMA A operand, activations as B: the two operands have
+    // the same lane layout, so this is just the argument order): lane (c, g) of tile (m, n) then holds output
+    // row row0 + 16m + c, columns 16(nt0+n) + 4g .. +3 - four consecutive floats, so bias, residual and the
+    // result move as 16-byte vectors (6 stores per wave tile instead of 24 dword stores).
+    // Epilogue operands are fetched NOW so their latency hides under the K loop.
+    f32x4 ebias[RN];
+    f32x4 eres[2][RN];
 #pragma unroll
     for (int n = 0; n < RN; ++n) {
-        const int col = (nt0 + ncl[n]) * 16 + c;
-        ebias[n] = p.bias ? p.bias[col] : 0.f;
+        const int col = (nt0 + ncl[n]) * 16 + 4 * g;
+        ebias[n] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int orow = row0 + 16 * m + 4 * g + r;
-                eres[m][n][r] = (p.resid && orow < p.M && col < p.n_store) ? p.resid[(size_t)orow * p.ldr + col] : 0.f;
-            }
+        for (int m = 0; m < 2; ++m) {
+            const int orow = row0 + 16 * m + c;
+            eres[m][n] = (p.resid && orow < p.M && col + 3 < p.n_store) ? *reinterpret_cast<const f32x4*>(p.resid + (size_t)orow * p.ldr + col)
+                                                                        : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     }
 
     const bf16x8* bseg = reinterpret_cast<const bf16x8*>(p.Bp);
@@ -149,8 +160,8 @@ __global__ __launch_bounds__(256) void mcg_gemm_bf16_kernel(McgGemmArgs p) {
             const bf16x8 A1 = mcg_pack_bf16(Ar[slot][1][0], Ar[slot][1][1]);
 #pragma unroll
             for (int n = 0; n < RN; ++n) {
-                acc[0][n] = mcg_mfma_bf16(A0, Br[slot][n], acc[0][n]);
-                acc[1][n] = mcg_mfma_bf16(A1, Br[slot][n], acc[1][n]);
+                acc[0][n] = mcg_mfma_bf16(Br[slot][n], A0, acc[0][n]);
+                acc[1][n] = mcg_mfma_bf16(Br[slot][n], A1, acc[1][n]);
             }
         };
         load_block(0, 0); load_block(1, 1); load_block(2, 2);
@@ -168,21 +179,30 @@ __global__ __launch_bounds__(256) void mcg_gemm_bf16_kernel(McgGemmArgs p) {
 #pragma unroll
     for (int n = 0; n < RN; ++n) {
         if (!nvalid[n]) continue;
-        const int col = (nt0 + n) * 16 + c;
+        const int col = (nt0 + n) * 16 + 4 * g;
         if (col >= p.n_store) continue;
-        const float bias = ebias[n];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m) {
+            const int orow = row0 + 16 * m + c;
+            if (orow >= p.M) continue;
+            f32x4 v = acc[m][n] + ebias[n];
+            if (p.act == MCG_ACT_SILU) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int orow = row0 + 16 * m + 4 * g + r;
-                if (orow >= p.M) continue;
-                float v = acc[m][n][r] + bias;
-                if (p.act == MCG_ACT_SILU) v = mcg_silu(v);
-                else if (p.act == MCG_ACT_RELU) v = fmaxf(v, 0.f);
-                v += eres[m][n][r];
-                p.C[(size_t)orow * p.ldc + col] = v;
+                for (int r = 0; r < 4; ++r) v[r] = mcg_silu(v[r]);
+            } else if (p.act == MCG_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
+            v += eres[m][n];
+            float* dst = p.C + (size_t)orow * p.ldc + col;
+            if (col + 3 < p.n_store) {
+                *reinterpret_cast<f32x4*>(dst) = v;       // (4-byte aligned is enough for a global dwordx4 store)
+            } else {                                       // ragged right edge (GCN: 210 columns)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (col + r < p.n_store) dst[r] = v[r];
+            }
+        }
     }
 }
 
@@ -195,7 +215,7 @@ __global__ __launch_bounds__(256) void mcg_gemm_kernel(McgGemmArgs p) {
     // ceil(waves / 4) workgroups - a 2-D grid rounds each row block up to whole workgroups and
     // can push a 243-workgroup problem over the 256-CU edge into a second round.
     const int wave_cols = (p.n_tiles + RN - 1) / RN;
-    const int wlin = blockIdx.x * 4 + wid;
+    const int wlin = MCG_GEMM_BLOCK(blockIdx.x, gridDim.x) * 4 + wid;
     if (wlin >= ((p.M + 31) / 32) * wave_cols) return;
     const int row0 = (wlin / wave_cols) * 32;
     const int nt0 = (wlin % wave_cols) * RN;
@@ -219,20 +239,23 @@ __global__ __launch_bounds__(256) void mcg_gemm_kernel(McgGemmArgs p) {
 #pragma unroll
         for (int n = 0; n < RN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // epilogue operands (bias, residual) are fetched NOW so their latency hides under the K loop
-    float ebias[RN];
-    float eres[2][RN][4];
+    // Accumulators are kept TRANSPOSED (weights as the MFMA A operand, activations as B: the two operands have
+    // the same lane layout, so this is just the argument order): lane (c, g) of tile (m, n) then holds output
+    // row row0 + 16m + c, columns 16(nt0+n) + 4g .. +3 - four consecutive floats, so bias, residual and the
+    // result move as 16-byte vectors (6 stores per wave tile instead of 24 dword stores).
+    // Epilogue operands are fetched NOW so their latency hides under the K loop.
+    f32x4 ebias[RN];
+    f32x4 eres[2][RN];
 #pragma unroll
     for (int n = 0; n < RN; ++n) {
-        const int col = (nt0 + ncl[n]) * 16 + c;
-        ebias[n] = p.bias ? p.bias[col] : 0.f;
+        const int col = (nt0 + ncl[n]) * 16 + 4 * g;
+        ebias[n] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int orow = row0 + 16 * m + 4 * g + r;
-                eres[m][n][r] = (p.resid && orow < p.M && col < p.n_store) ? p.resid[(size_t)orow * p.ldr + col] : 0.f;
-            }
+        for (int m = 0; m < 2; ++m) {
+            const int orow = row0 + 16 * m + c;
+            eres[m][n] = (p.resid && orow < p.M && col + 3 < p.n_store) ? *reinterpret_cast<const f32x4*>(p.resid + (size_t)orow * p.ldr + col)
+                                                                        : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     }
 
     const float* bseg = p.Bp;
@@ -270,7 +293,7 @@ __global__ __launch_bounds__(256) void mcg_gemm_kernel(McgGemmArgs p) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int n = 0; n < RN; ++n) acc[m][n] = mcg_mfma(Ar[slot][m][s], Br[slot][n][s], acc[m][n]);
+                    for (int n = 0; n < RN; ++n) acc[m][n] = mcg_mfma(Br[slot][n][s], Ar[slot][m][s], acc[m][n]);
         };
 #pragma unroll
         for (int i = 0; i < RING; ++i) load_group(i, i);
@@ -299,32 +322,40 @@ __global__ __launch_bounds__(256) void mcg_gemm_kernel(McgGemmArgs p) {
 #pragma unroll
             for (int n = 0; n < RN; ++n) {
                 const float b = bt[(size_t)st * p.n_tiles * 64 + ncl[n] * 64];
-                acc[0][n] = mcg_mfma(av0, b, acc[0][n]);
-                acc[1][n] = mcg_mfma(av1, b, acc[1][n]);
+                acc[0][n] = mcg_mfma(b, av0, acc[0][n]);
+                acc[1][n] = mcg_mfma(b, av1, acc[1][n]);
             }
         }
         bseg += mcg_pack4_floats(K, p.n_tiles);
     }
 
-    // epilogue: C/D layout  col = lane & 15, row = 4*(lane>>4) + r
 #pragma unroll
     for (int n = 0; n < RN; ++n) {
         if (!nvalid[n]) continue;
-        const int col = (nt0 + n) * 16 + c;
+        const int col = (nt0 + n) * 16 + 4 * g;
         if (col >= p.n_store) continue;
-        const float bias = ebias[n];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m) {
+            const int orow = row0 + 16 * m + c;
+            if (orow >= p.M) continue;
+            f32x4 v = acc[m][n] + ebias[n];
+            if (p.act == MCG_ACT_SILU) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int orow = row0 + 16 * m + 4 * g + r;
-                if (orow >= p.M) continue;
-                float v = acc[m][n][r] + bias;
-                if (p.act == MCG_ACT_SILU) v = mcg_silu(v);
-                else if (p.act == MCG_ACT_RELU) v = fmaxf(v, 0.f);
-                v += eres[m][n][r];
-                p.C[(size_t)orow * p.ldc + col] = v;
+                for (int r = 0; r < 4; ++r) v[r] = mcg_silu(v[r]);
+            } else if (p.act == MCG_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
+            v += eres[m][n];
+            float* dst = p.C + (size_t)orow * p.ldc + col;
+            if (col + 3 < p.n_store) {
+                *reinterpret_cast<f32x4*>(dst) = v;       // (4-byte aligned is enough for a global dwordx4 store)
+            } else {                                       // ragged right edge (GCN: 210 columns)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (col + r < p.n_store) dst[r] = v[r];
+            }
+        }
     }
 }
 

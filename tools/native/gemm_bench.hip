@@ -9,6 +9,8 @@
 #ifndef RINGS
 #define RINGS 3
 #endif
+__global__ void k_empty(float* p) { if (p == nullptr) p[0] = 1.f; }
+
 template <int RN, int RING>
 static void launch(const McgGemmArgs& a, hipStream_t s) {
     const int rowblocks = (a.M + 31) / 32;
@@ -69,6 +71,31 @@ int main(int argc, char** argv) {
             float ms; hipEventElapsedTime(&ms, e0, e1);
             printf("M=%d ring=%d %-26s RN=%d  %.1f us  %.1f TFLOP/s\n", M, RINGS, names[which], rn, ms * 1e3 / iters, flops[which] / (ms * 1e-3 / iters) / 1e12);
         }
+    }
+    // duration vs K for the Pab shape (RN = 3): separates the per-launch floor from the per-k cost
+    for (int K : {16, 112, 208, 304, 420}) {
+        auto run = [&](int n) {
+            for (int i = 0; i < n; ++i) { McgGemmArgs g = args(0, i % SETS); g.K1 = K; launch<3, RINGS>(g, s); }
+        };
+        run(SETS);
+        hipStreamSynchronize(s);
+        hipEventRecord(e0, s);
+        run(iters);
+        hipEventRecord(e1, s);
+        hipStreamSynchronize(s);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("M=%d Pab shape, K=%3d: %.1f us per launch (MFMA chain %.1f us)\n", M, K, ms * 1e3 / iters, K / 4 * 6 * 32 / 2.39e3);
+    }
+    {   // launch floor: an empty kernel with the same grid, back to back on the stream
+        auto run = [&](int n) { for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_empty, dim3(243), dim3(256), 0, s, pab); };
+        run(SETS);
+        hipStreamSynchronize(s);
+        hipEventRecord(e0, s);
+        run(iters);
+        hipEventRecord(e1, s);
+        hipStreamSynchronize(s);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("empty kernel, 243 workgroups: %.2f us per launch\n", ms * 1e3 / iters);
     }
     return 0;
 }
