@@ -1,8 +1,9 @@
 """Oracle: Gaussian-volume shape Tanimoto on a grid (test infrastructure - see oracle/__init__.py).
 
-Restates `tanimoto_score` and its helpers (cheminformatics/shape_similarity.py:327-334, 405-492).
-The principal-frame alignment that precedes it in `evaluate_samples` (clique enumeration,
-shape_similarity.py:18-322) is host combinatorics and is not restated here.
+Restates `tanimoto_score` and its helpers (cheminformatics/shape_similarity.py:327-334, 405-492) and the
+principal shape frame that precedes it in `evaluate_samples` (`get_shape_quadrupole_for_molecule`,
+shape_similarity.py:18-402: Gaussian inclusion-exclusion over mutually-neighbouring atom subsets up to order 6).
+Pinned to tests/golden/shape_tanimoto.npz and shape_quadrupole.npz (generated from the reference).
 """
 from __future__ import annotations
 
@@ -74,3 +75,82 @@ def best_orientation_score(ref_coord: torch.Tensor, cand_coord: torch.Tensor):
         if sc > best:
             best, which = sc, k + 1
     return best, which
+
+
+# ------------------------------------------------------------------------- principal shape frame
+def neighbour_matrix(coord: torch.Tensor, threshold: float) -> torch.Tensor:
+    """shape_similarity.py:244-260: 0 < dist < threshold (no self loops)."""
+    d = torch.sqrt(((coord.unsqueeze(1) - coord.unsqueeze(0)) ** 2).sum(2))
+    return (d < threshold) & (d > 0)
+
+
+def cliques_of_order(adj: torch.Tensor, order: int):
+    """All index tuples i1 < i2 < ... < i_order whose members are mutual neighbours
+    (find_r_cliques_fast, shape_similarity.py:269-311), in lexicographic order."""
+    n = adj.size(0)
+    out = []
+
+    def grow(members, cand):
+        if len(members) == order:
+            out.append(list(members))
+            return
+        for v in cand:
+            grow(members + [v], [u for u in cand if u > v and bool(adj[v, u])])
+
+    grow([], list(range(n)))
+    return torch.tensor(out, dtype=torch.long).reshape(-1, order)
+
+
+def product_of_gaussians(centers: torch.Tensor, alpha: float, amplitude: float):
+    """shape_similarity.py:205-230: centre, exponent and amplitude of a product of n equal Gaussians."""
+    n = centers.size(1)
+    gamma = (centers ** 2).sum(-1).sum(-1) - (centers.sum(1) ** 2).sum(-1) / n
+    return centers.mean(1), n * alpha, amplitude ** n * torch.exp(-alpha * gamma)
+
+
+def _moments(points: torch.Tensor, combos, alpha: float, amplitude: float):
+    """Zeroth/first/second Gaussian-volume moments with inclusion-exclusion signs
+    (shape_similarity.py:36-84 for volume/first, :88-129 for the second moments; integrals :337-402)."""
+    def acc(c, a, amp):
+        k = (math.pi / a) ** 1.5
+        vol = (amp * k).sum() if torch.is_tensor(amp) else amp * k * c.size(0)
+        amp_col = amp.unsqueeze(-1) if torch.is_tensor(amp) else amp
+        first = (amp_col * c * k).sum(0)
+        ii = (amp_col * k * (c ** 2 + 1 / (2 * a))).sum(0)
+        ij = torch.stack([(amp_col.squeeze(-1) if torch.is_tensor(amp) else amp) * p * k for p in
+                          (c[:, 0] * c[:, 1], c[:, 0] * c[:, 2], c[:, 1] * c[:, 2])]).sum(-1)
+        return vol, first, ii, ij
+    vol, first, ii, ij = acc(points, alpha, amplitude)
+    for order, idx in combos.items():
+        if idx.numel() == 0:
+            continue
+        c, a, amp = product_of_gaussians(points[idx], alpha, amplitude)
+        v, f, d, o = acc(c, a, amp)
+        sign = (-1) ** (order - 1)
+        vol, first, ii, ij = vol + sign * v, first + sign * f, ii + sign * d, ij + sign * o
+    return vol, first, ii, ij
+
+
+def _tensor3(ii, ij, vol):
+    return torch.tensor([[float(ii[0]), float(ij[0]), float(ij[1])],
+                         [float(ij[0]), float(ii[1]), float(ij[2])],
+                         [float(ij[1]), float(ij[2]), float(ii[2])]]) / vol
+
+
+def shape_quadrupole(coordinates: torch.Tensor, amplitude: float = AMPLITUDE, atom_radius: float = ATOM_RADIUS,
+                     n_terms: int = 6, neighbour_threshold: float = 2 * AMPLITUDE):
+    """get_shape_quadrupole_for_molecule (shape_similarity.py:18-202): (principal moments, descending;
+    coordinates in the principal shape frame)."""
+    coordinates = coordinates.to(torch.float32)
+    alpha = get_alpha(atom_radius, amplitude)
+    adj = neighbour_matrix(coordinates, neighbour_threshold)
+    combos = {k: cliques_of_order(adj, k) for k in range(2, n_terms + 1)}
+    vol, first, _, _ = _moments(coordinates, combos, alpha, amplitude)
+    centred = coordinates - first / vol                                  # :86-89
+    _, _, ii, ij = _moments(centred, combos, alpha, amplitude)
+    _, vecs = torch.linalg.eigh(_tensor3(ii, ij, vol))                  # :143-144
+    rotated = centred @ vecs
+    _, _, ii, ij = _moments(rotated, combos, alpha, amplitude)
+    main = torch.diag(_tensor3(ii, ij, vol))                             # :184-199
+    moments, order = torch.sort(main, descending=True)
+    return moments, rotated[:, order]

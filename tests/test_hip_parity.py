@@ -690,3 +690,30 @@ def test_handles_are_freed(edm_sd):
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 << 20, (free0, free1)
+
+
+def test_evaluate_shape_vs_reference_pipeline():
+    """Shape half of evaluate_samples (pipeline.py:30-85) on the device: principal frames + four-orientation
+    HIP overlap search against the reference's frames / best scores (golden)."""
+    from ml_conformer_generator_amd.cheminformatics import evaluate_shape, shape_quadrupole_batch
+    g = load_golden("shape_quadrupole.npz")
+    names = ["yibfeu", "walk27", "paba", "ceyyag"]
+    N = 27
+    coords, nn = torch.zeros(len(names), N, 3), []
+    for i, n in enumerate(names):
+        x = g[f"xyz_{n}"]
+        coords[i, : x.shape[0]] = x + torch.tensor([0.7, -1.1, 0.4])       # evaluate_shape re-centres
+        nn.append(x.shape[0])
+    nn = torch.tensor(nn)
+    mom, frames = shape_quadrupole_batch(coords - torch.tensor([0.7, -1.1, 0.4]) * (torch.arange(N).view(1, N, 1) < nn.view(-1, 1, 1)),
+                                         nn, device=DEV)
+    for i, n in enumerate(names):
+        assert float((mom[i].cpu() - g[f"moments_{n}"]).abs().max()) < 2e-5, n
+        assert float((frames[i, : int(nn[i])].cpu() - g[f"frame_{n}"]).abs().max()) < 2e-5, n
+    ref_pf, res = evaluate_shape(g["xyz_ceyyag"], coords, nn, device=DEV)
+    assert float((ref_pf - g["frame_ceyyag"]).abs().max()) < 2e-5
+    for i, key in ((0, "best__ceyyag__yibfeu"), (1, "best__ceyyag__walk27")):
+        assert abs(res[i]["shape_tanimoto"] - float(g[key][0])) < 2e-4, key
+        assert res[i]["orientation"] == int(g[key][1]), key
+    assert res[3]["orientation"] == 0 and abs(res[3]["shape_tanimoto"] - 1.0) < 1e-4      # the reference itself
+    assert res[2]["coords"].shape == (10, 3)

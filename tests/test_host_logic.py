@@ -165,3 +165,23 @@ def test_inertial_fragment_matching_front_end_matches_reference():
     assert torch.allclose(ms, g["moi_shift"], rtol=1e-6, atol=1e-5)
     with pytest.raises(ValueError, match="fewer atoms than minimum"):
         MU.ifm_prepare_gen_fragment_context(g["frag_x"], g["ref_context"], norms, g["n_nodes"], 25, 8, torch.device("cpu"))
+
+
+def test_batched_principal_frames_match_reference_on_cpu_tensors():
+    """The batched frame construction (clique growth as index tensors, fp64 per-molecule sums) is plain tensor
+    algebra around the HIP overlap kernel; on CPU tensors it must reproduce the reference's frames."""
+    from conftest import load_golden
+    from ml_conformer_generator_amd.cheminformatics import shape_quadrupole_batch
+    g = load_golden("shape_quadrupole.npz")
+    names = ["ceyyag", "yibfeu", "paba", "walk12", "walk27"]
+    N = 27
+    coords, nn = torch.zeros(len(names), N, 3), []
+    for i, n in enumerate(names):
+        x = g[f"xyz_{n}"]
+        coords[i, : x.shape[0]] = x
+        nn.append(x.shape[0])
+    mom, frames = shape_quadrupole_batch(coords, torch.tensor(nn), device="cpu")
+    for i, n in enumerate(names):
+        assert float((mom[i] - g[f"moments_{n}"]).abs().max()) < 2e-5, n
+        assert float((frames[i, : nn[i]] - g[f"frame_{n}"]).abs().max()) < 2e-5, n
+        assert float(frames[i, nn[i]:].abs().max() if nn[i] < N else 0.0) == 0.0

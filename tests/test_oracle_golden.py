@@ -135,3 +135,20 @@ def test_shape_tanimoto_oracle_matches_reference():
         mine = [SO.tanimoto_score(xa, xb)] + [SO.tanimoto_score(xa, SO.rotate_coord(xb, ang)) for ang in angs]
         assert np.abs(np.array(mine) - g[key].numpy()).max() < 1e-7, key
     assert abs(SO.tanimoto_score(g["xyz_ceyyag"], g["xyz_ceyyag"]) - 1.0) < 1e-6
+
+
+def test_shape_quadrupole_oracle_matches_reference():
+    """Principal shape frames (get_shape_quadrupole_for_molecule, shape_similarity.py:18-202): the oracle
+    restatement against the reference's outputs - same operations in the same order, so the tolerance is tight
+    (moments 1e-5; coordinates 1e-5 except crown_6, whose two largest moments differ by < 1 %)."""
+    from oracle import shape_oracle as SO
+    g = load_golden("shape_quadrupole.npz")
+    for name in ("paba", "ceyyag", "crown_6", "walk12", "yibfeu"):
+        mom, frame = SO.shape_quadrupole(g[f"xyz_{name}"])
+        assert float((mom - g[f"moments_{name}"]).abs().max()) < 1e-5, name
+        assert float((frame - g[f"frame_{name}"]).abs().max()) < (1e-3 if name == "crown_6" else 1e-5), name
+    # the orientation search of evaluate_samples on principal frames
+    for key in ("best__ceyyag__yibfeu", "best__yibfeu__paba"):
+        _, a, b = key.split("__")
+        best, which = SO.best_orientation_score(g[f"frame_{a}"], g[f"frame_{b}"])
+        assert abs(best - float(g[key][0])) < 1e-6 and which == int(g[key][1])

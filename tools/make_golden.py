@@ -268,6 +268,31 @@ def main():
         tan[f"{a}__{b}"] = torch.tensor(scores, dtype=torch.float64)
     save("shape_tanimoto.npz", alpha=ss.ALPHA, **{f"xyz_{k}": v for k, v in mols.items()}, **tan)
 
+    # 6d. principal shape frames (get_shape_quadrupole_for_molecule) and the orientation search of
+    #     evaluate_samples (cheminformatics/pipeline.py:40-85) on them
+    g = torch.Generator().manual_seed(77)
+    walk = {}
+    for n_at in (12, 27):
+        stepv = torch.nn.functional.normalize(torch.randn(n_at, 3, generator=g), dim=1) * 1.45
+        xyz = torch.cumsum(stepv, 0)
+        walk[f"walk{n_at}"] = xyz - xyz.mean(0)
+    frames = {}
+    allm = dict(mols, **walk)
+    for name, xyz in allm.items():
+        mom, pts = ss.get_shape_quadrupole_for_molecule(coordinates=xyz)
+        frames[name] = (mom, pts)
+    ev = {}
+    for a, b in (("ceyyag", "yibfeu"), ("ceyyag", "walk27"), ("yibfeu", "paba"), ("walk12", "ceyyag")):
+        ref_pf, cand_pf = frames[a][1], frames[b][1]
+        best, which = ss.tanimoto_score(ref_pf, cand_pf), 0
+        for k, ang in enumerate(angs[1:]):
+            sc = ss.tanimoto_score(ref_pf, ss.rotate_coord(coord=cand_pf, angles=ang))
+            if sc > best:
+                best, which = sc, k + 1
+        ev[f"best__{a}__{b}"] = torch.tensor([best, which], dtype=torch.float64)
+    save("shape_quadrupole.npz", **{f"xyz_{k}": v for k, v in allm.items()},
+         **{f"moments_{k}": v[0] for k, v in frames.items()}, **{f"frame_{k}": v[1] for k, v in frames.items()}, **ev)
+
     # 7. AdjMatSeer (a15), synthetic weights seed 4321
     gsd = W.synth_adj_mat_seer_state_dict(4321)
     gcn = ams.AdjMatSeer(dimension=42, n_hidden=2048, embedding_dim=64, num_embeddings=36, num_bond_types=5).eval()
