@@ -362,15 +362,31 @@ __global__ __launch_bounds__(256) void mcg_gemm_kernel(McgGemmArgs p) {
 static inline hipError_t mcg_gemm_launch(const McgGemmArgs& a, hipStream_t s, bool bf16 = false) {
     if (a.M <= 0) return hipSuccess;
     const int rowblocks = (a.M + 31) / 32;
-    // wave tile width RN in {1,2,3}: minimise (rounds of 256 four-wave workgroups) x (work per wave ~ RN);
-    // ties go to the wider tile (fewer redundant A loads)
+    // Wave tile width RN in {1,2,3} from a measured cost model (tools/native/gemm_bench.hip, MI355X; us of loop
+    // time per wave and per 420 of K): with at most one wave per SIMD a wave costs u1[RN]; with many waves per
+    // SIMD the SIMD retires one wave per uinf[RN] (the 3-wide tile degrades most when waves share a SIMD).
+    // cost = u1 for r <= 1, else max(ceil(r) * u1, r * uinf), r = waves / 1024 SIMDs.  It reproduces the measured-best width for
+    // M = 1.7k .. 13k on all three node-GEMM shapes (the old "rounds x RN" rule picked RN = 3 at config 3:
+    // 80 us instead of 62 us for the Pab GEMM).
     int rn = 1;
-    long best = -1;
-    for (int cand = 1; cand <= 3; ++cand) {
-        const long waves = (long)rowblocks * ((a.n_tiles + cand - 1) / cand);
-        const long wgs = (waves + 3) / 4;
-        const long cost = ((wgs + 255) / 256) * cand;
-        if (best < 0 || cost <= best) { best = cost; rn = cand; }
+    if (bf16) {
+        // bf16 kernels: minimise (rounds of 256 four-wave workgroups) x (work per wave ~ RN); ties go to the wider tile
+        long best = -1;
+        for (int cand = 1; cand <= 3; ++cand) {
+            const long wgs = ((long)rowblocks * ((a.n_tiles + cand - 1) / cand) + 3) / 4;
+            const long cost = ((wgs + 255) / 256) * cand;
+            if (best < 0 || cost <= best) { best = cost; rn = cand; }
+        }
+    } else {
+        static const double u1[4] = {0, 3.7, 5.0, 8.9}, uinf[4] = {0, 5.8, 10.4, 21.9};
+        double best = -1;
+        for (int cand = 1; cand <= 3; ++cand) {
+            const double r = (double)rowblocks * ((a.n_tiles + cand - 1) / cand) / 1024.0;
+            const double up = (double)(long)(r + 0.999999);
+            const double c1 = up * u1[cand], c2 = r * uinf[cand];
+            const double cost = (r <= 1.0 || c1 > c2) ? c1 : c2;      // one wave per SIMD or less: no sharing penalty
+            if (best < 0 || cost < best) { best = cost; rn = cand; }
+        }
     }
     if (const char* e = getenv("MCG_GEMM_RN")) { const int v = atoi(e); if (v >= 1 && v <= 3) rn = v; }
     const long waves = (long)rowblocks * ((a.n_tiles + rn - 1) / rn);
