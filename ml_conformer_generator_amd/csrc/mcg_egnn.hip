@@ -1465,14 +1465,7 @@ int mcg_plan_N(const mcg_plan* p) { return p->N; }
 const int* mcg_plan_n_nodes(const mcg_plan* p) { return p->n_nodes; }
 
 // =========================================================================== C ABI
-extern "C" {
-
-int mcg_egnn_create(const float* const* tensors, int n_tensors, int hidden, int n_blocks, mcg_egnn** out) {
-    if (!tensors || !out || hidden != H || n_blocks < 1 || n_tensors != 4 + n_blocks * 25) {
-        mcg_set_error("mcg_egnn_create: bad arguments (hidden must be %d, n_tensors = 4 + 25*n_blocks)", H);
-        return MCG_ERR_ARG;
-    }
-    mcg_egnn* m = new mcg_egnn();
+static int egnn_build(mcg_egnn* m, const float* const* tensors, int n_blocks) {
     m->n_blocks = n_blocks;
     const float* const* t = tensors;
     // embedding (420x12) / bias, embedding_out (12x420) / bias
@@ -1480,17 +1473,20 @@ int mcg_egnn_create(const float* const* tensors, int n_tensors, int hidden, int 
     for (int n = 0; n < H; ++n)
         for (int k = 0; k < IN_NF; ++k) v[(size_t)k * HP + n] = t[0][(size_t)n * IN_NF + k];
     if (int e = upload(v, &m->emb_wT)) return e;
+    m->allocs.push_back(m->emb_wT);
     v.assign(HP, 0.f);
     for (int n = 0; n < H; ++n) v[n] = t[1][n];
     if (int e = upload(v, &m->emb_b)) return e;
+    m->allocs.push_back(m->emb_b);
     v.assign((size_t)IN_NF * HP, 0.f);
     for (int o = 0; o < IN_NF; ++o)
         for (int k = 0; k < H; ++k) v[(size_t)o * HP + k] = t[2][(size_t)o * H + k];
     if (int e = upload(v, &m->out_w)) return e;
+    m->allocs.push_back(m->out_w);
     v.assign(16, 0.f);
     for (int o = 0; o < IN_NF; ++o) v[o] = t[3][o];
     if (int e = upload(v, &m->out_b)) return e;
-    m->allocs.insert(m->allocs.end(), {(void*)m->emb_wT, (void*)m->emb_b, (void*)m->out_w, (void*)m->out_b});
+    m->allocs.push_back(m->out_b);
     m->gcl_edge.resize(2 * n_blocks);
     m->gcl_node.resize(2 * n_blocks);
     m->equiv.resize(n_blocks);
@@ -1505,6 +1501,22 @@ int mcg_egnn_create(const float* const* tensors, int n_tensors, int hidden, int 
         const float* const* q = t + idx;       // coord0.w,b coord2.w,b coord4.w
         if (int e = build_edge_layer(m, m->equiv[b], q[0], q[1], q[2], q[3], q[4], 0.f)) return e;
         idx += 5;
+    }
+    return MCG_OK;
+}
+
+
+extern "C" {
+
+int mcg_egnn_create(const float* const* tensors, int n_tensors, int hidden, int n_blocks, mcg_egnn** out) {
+    if (!tensors || !out || hidden != H || n_blocks < 1 || n_tensors != 4 + n_blocks * 25) {
+        mcg_set_error("mcg_egnn_create: bad arguments (hidden must be %d, n_tensors = 4 + 25*n_blocks)", H);
+        return MCG_ERR_ARG;
+    }
+    mcg_egnn* m = new mcg_egnn();
+    if (int e = egnn_build(m, tensors, n_blocks)) {
+        mcg_egnn_destroy(m);          // frees whatever was uploaded before the failure
+        return e;
     }
     *out = m;
     return MCG_OK;
@@ -1616,7 +1628,7 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
     e |= upload_i(nn, &p->n_nodes); e |= upload_i(node_off, &p->node_off); e |= upload_i(row_off, &p->row_off);
     e |= upload_i(tile_mol, &p->tile_mol); e |= upload_i(wave_nf, &p->wave_nf); e |= upload_i(wave_poff, &p->wave_poff);
     e |= upload_i(node_mol, &p->node_mol);
-    if (e) { delete p; return MCG_ERR_HIP; }
+    if (e) { mcg_plan_destroy(p); return MCG_ERR_HIP; }
     p->allocs.insert(p->allocs.end(), {(void*)p->n_nodes, (void*)p->node_off, (void*)p->row_off, (void*)p->tile_mol,
                                        (void*)p->wave_nf, (void*)p->wave_poff, (void*)p->node_mol});
     const size_t M1 = (size_t)(p->M > 0 ? p->M : 1);
@@ -1625,8 +1637,13 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
         {&p->x, M1 * 4}, {&p->x0, M1 * 4}, {&p->h, M1 * HP + 64}, {&p->h2, M1 * HP + 64}, {&p->pab, M1 * 2 * HP + 64},
         {&p->agg, M1 * HP + 64}, {&p->t1, M1 * HP + 64}, {&p->P, (size_t)(p->n_pslots + 1) * HP}, {&p->Px, (size_t)(p->n_pslots + 1) * 4}};
     for (auto& b : bufs) {
-        MCG_HIP(hipMalloc((void**)b.ptr, b.n * sizeof(float)));
-        MCG_HIP(hipMemset(*b.ptr, 0, b.n * sizeof(float)));
+        if (hipMalloc((void**)b.ptr, b.n * sizeof(float)) != hipSuccess || hipMemset(*b.ptr, 0, b.n * sizeof(float)) != hipSuccess) {
+            mcg_set_error("mcg_plan_create: out of device memory (%zu floats)", b.n);
+            (void)hipGetLastError();
+            if (*b.ptr) p->allocs.push_back(*b.ptr);
+            mcg_plan_destroy(p);
+            return MCG_ERR_HIP;
+        }
         p->allocs.push_back(*b.ptr);
     }
     *out = p;
@@ -1645,9 +1662,21 @@ void mcg_plan_destroy(mcg_plan* p) {
     delete p;
 }
 
+static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, int edge_mt);
+
 int mcg_plan_create(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_plan** out) {
-    if (int e = plan_create_single(B, N, n_nodes_host, edge_mt, out)) return e;
-    mcg_plan* p = *out;
+    mcg_plan* p = nullptr;
+    if (int e = plan_create_single(B, N, n_nodes_host, edge_mt, &p)) return e;
+    if (int e = plan_finish(p, B, N, n_nodes_host, edge_mt)) {
+        mcg_plan_destroy(p);          // streams, events, sub-plans and buffers created so far
+        return e;
+    }
+    *out = p;
+    return MCG_OK;
+}
+
+// graph staging buffer, capture stream and the optional split into molecule ranges
+static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, int edge_mt) {
     MCG_HIP(hipMalloc((void**)&p->t_buf, (size_t)B * sizeof(float)));
     p->allocs.push_back(p->t_buf);
     MCG_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
@@ -1669,7 +1698,7 @@ int mcg_plan_create(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_
             while (b1 < B && cum[b1] < target) ++b1;
         }
         mcg_plan* sub = nullptr;
-        if (int e = plan_create_single(b1 - b0, N, n_nodes_host + b0, edge_mt, &sub)) { mcg_plan_destroy(p); return e; }
+        if (int e = plan_create_single(b1 - b0, N, n_nodes_host + b0, edge_mt, &sub)) return e;
         p->subs.push_back(sub);
         p->sub_b0.push_back(b0);
         hipStream_t st; hipEvent_t ev;
