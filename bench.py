@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-phi-calls", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32x6"],
                     help="bf16 = opt-in reduced-precision MFMA operands (configs[4]); the default bench line is fp32")
     ap.add_argument("--fragment", action="store_true",
                     help="configs[4] sampler: inpainting around a fixed 8-atom fragment (6 C + 2 Cl), resample_steps=1, "

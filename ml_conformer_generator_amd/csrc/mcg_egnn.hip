@@ -828,17 +828,28 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds_bf16(EdgeAr
 // 7x and every B fragment 4x from registers (11 fragment reads per 28 MFMAs).  The A operand (layer-1 finish
 // + SiLU, rounded to bf16) of row tile w is produced once by wave w and shared through LDS; the gate /
 // coordinate-head dot product is completed across the waves through LDS in fixed order.
-constexpr int W64_A_FLOATS = 2 * 4 * 64 * 4;          // A tile ring: [2][4 row tiles][64 lanes] x 16 B
-constexpr int W64_LDS_FLOATS = 2 * HP + W64_A_FLOATS + 4 * 64 + 64 * 4;       // no B staging: 13 KB
+constexpr int W64_A_FLOATS = 2 * 4 * 64 * 4;          // A tile ring: [2][4 row tiles][64 lanes] x 16 B (per operand part)
+constexpr int W64_KP = 32 * ((H + 31) / 32);            // 448: k range of the padded 32-k blocks
+template <int SPLIT> constexpr int w64_lds_floats() { return 2 * HP + 2 * W64_KP + SPLIT * W64_A_FLOATS + 4 * 64 + 64 * 4; }   // 17 / 33 KiB
 
-template <bool EQUIV>
+// SPLIT = 1: bf16 operands (one product).  SPLIT = 3: "f32x6" - every fp32 operand is carried as the exact sum of
+// three bf16 parts (a = a1 + a2 + a3, |a2| <= 2^-8 |a|, |a3| <= 2^-16 |a|; same for the weights, split on the
+// host) and the six partial products of weight >= 2^-16 (a1 b1, a2 b1, a3 b1, a1 b2, a2 b2, a1 b3) are accumulated
+// in fp32: the dropped terms are <= 2^-23 relative, i.e. the contraction is fp32-accurate, on a matrix pipe that is
+// 16x faster per k than v_mfma_f32_16x16x4_f32 (6/16 of the exact kernel's matrix time).  The weight parts are
+// streamed part-major per 32-k block (stage = kb*3 + part); part p meets the activation parts 0 .. 2-p.
+template <bool EQUIV, int SPLIT>
 __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
-    __shared__ __attribute__((aligned(16))) float lds[W64_LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[w64_lds_floats<SPLIT>()];
     float* const par = lds;                                              // b2 | wv
-    bf16x8* const a_lds = reinterpret_cast<bf16x8*>(par + 2 * HP);       // [2][4][64]
-    float* const xchg = par + 2 * HP + W64_A_FLOATS;                     // [4 waves][64 rows]
+    float* const wdl = par + 2 * HP;                                     // wd | wd0 (layer-1 distance weights): read at
+                                                                         // A-generation time instead of being held in
+                                                                         // 16 VGPRs across a whole k-block
+    bf16x8* const a_lds = reinterpret_cast<bf16x8*>(wdl + 2 * W64_KP);   // [2][SPLIT][4][64]
+    float* const xchg = wdl + 2 * W64_KP + SPLIT * W64_A_FLOATS;         // [4 waves][64 rows]
     float* const ri = xchg + 4 * 64;                                     // [64 rows][4]: seg, ux, uy, uz
     for (int i = threadIdx.x; i < HP; i += 256) { par[i] = p.b2[i]; par[HP + i] = p.wv[i]; }
+    for (int i = threadIdx.x; i < W64_KP; i += 256) { wdl[i] = p.wd[i]; wdl[W64_KP + i] = p.wd0[i]; }
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
@@ -872,10 +883,13 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
             dst[0] = __int_as_float(sg); dst[1] = ux; dst[2] = uy; dst[3] = uz;
         }
     }
-    const float* pa = p.pab + (size_t)vi * (2 * HP) + 8 * g;
-    const float* pb = p.pab + (size_t)vj * (2 * HP) + HP + 8 * g;
-    const float* wdp = p.wd + 8 * g;
-    const float* w0p = p.wd0 + 8 * g;
+    // Operand addresses are (buffer descriptor in SGPRs) + (one 32-bit lane offset) + (scalar block offset): as
+    // 64-bit per-lane pointers hipcc keeps ~20 VGPRs of addresses alive and the f32x6 variant spills.
+    const unsigned oa = (unsigned)(vi * (2 * HP) + 8 * g) * 4u;
+    const unsigned ob = (unsigned)(vj * (2 * HP) + HP + 8 * g) * 4u;
+    const __amdgpu_buffer_rsrc_t rs_pab = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pab), 0, 0xffffffff, 0x00020000);
+    const float* wdp = wdl + 8 * g;
+    const float* w0p = wdl + W64_KP + 8 * g;
 
     f32x4 acc[4][NS_T];
 #pragma unroll
@@ -886,68 +900,110 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
     // B fragments: straight from global/L2 into a 2-deep REGISTER ring (each wave streams only the 7 column
     // tiles it owns; per workgroup that is the same 363 KB of W2 an LDS stage would move, without the stage's
     // one-block latency budget: an LDS-DMA issued at the top of a 450-cycle bf16 block has not landed when the
-    // next block starts, which is what bounds k_edge_lds_bf16).
-    const bf16x8* bsrc = reinterpret_cast<const bf16x8*>(p.Bp) + lane;
-    int btile[NS_T];
-#pragma unroll
-    for (int i = 0; i < NS_T; ++i) btile[i] = (wid + 4 * i < NT ? wid + 4 * i : NT - 1) * 64;
+    // next block starts, which is what bounds k_edge_lds_bf16).  One ring stage = the wave's 7 fragments of one
+    // (k-block, weight part): tiles wid, wid+4, .., wid+24 (the last one clamped to 26 for wave 3, result unused).
+    constexpr int NSTAGE = KB16 * SPLIT;
+    constexpr int STAGE_BYTES = NT * 64 * 16;
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Bp), 0, NSTAGE * STAGE_BYTES, 0x00020000);
+    const unsigned ov = (unsigned)(wid * 64 + lane) * 16u;
+    const unsigned ov6 = (unsigned)((wid + 24 < NT ? wid + 24 : NT - 1) * 64 + lane) * 16u;
     bf16x8 Bq[2][NS_T];
-    auto load_b = [&](bf16x8 (&dst)[NS_T], int kb) {
-        kb = kb < KB16 ? kb : KB16 - 1;
+    auto ld16 = [](const __amdgpu_buffer_rsrc_t& r, unsigned voff, int soff) {
+        return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0);
+    };
+    auto load_b = [&](bf16x8 (&dst)[NS_T], int stage) {
+        stage = stage < NSTAGE ? stage : NSTAGE - 1;
+        const int base = stage * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < NS_T; ++i) dst[i] = bsrc[(size_t)kb * NT * 64 + btile[i]];
+        for (int i = 0; i < NS_T - 1; ++i) dst[i] = __builtin_bit_cast(bf16x8, ld16(rs_b, ov, base + i * 4 * 64 * 16));
+        dst[NS_T - 1] = __builtin_bit_cast(bf16x8, ld16(rs_b, ov6, base));
     };
-    auto load_a = [&](int kb, f32x4 (&v)[8]) {
+    auto load_a = [&](int kb, f32x4 (&v)[4]) {
         kb = kb < KB16 ? kb : KB16 - 1;
-        v[0] = *reinterpret_cast<const f32x4*>(pa + 32 * kb);  v[1] = *reinterpret_cast<const f32x4*>(pa + 32 * kb + 4);
-        v[2] = *reinterpret_cast<const f32x4*>(pb + 32 * kb);  v[3] = *reinterpret_cast<const f32x4*>(pb + 32 * kb + 4);
-        v[4] = *reinterpret_cast<const f32x4*>(wdp + 32 * kb); v[5] = *reinterpret_cast<const f32x4*>(wdp + 32 * kb + 4);
-        v[6] = *reinterpret_cast<const f32x4*>(w0p + 32 * kb); v[7] = *reinterpret_cast<const f32x4*>(w0p + 32 * kb + 4);
+        v[0] = __builtin_bit_cast(f32x4, ld16(rs_pab, oa, 128 * kb));  v[1] = __builtin_bit_cast(f32x4, ld16(rs_pab, oa, 128 * kb + 16));
+        v[2] = __builtin_bit_cast(f32x4, ld16(rs_pab, ob, 128 * kb));  v[3] = __builtin_bit_cast(f32x4, ld16(rs_pab, ob, 128 * kb + 16));
     };
-    auto agen = [&](const f32x4 (&v)[8]) -> bf16x8 {
+    // layer-1 finish + SiLU of my row tile for one k-block, written to ring half `half` as SPLIT bf16 parts
+    auto agen_store = [&](const f32x4 (&v)[4], int kb, int half) {
+        const f32x4 wd_lo = *reinterpret_cast<const f32x4*>(wdp + 32 * kb), wd_hi = *reinterpret_cast<const f32x4*>(wdp + 32 * kb + 4);
+        const f32x4 w0_lo = *reinterpret_cast<const f32x4*>(w0p + 32 * kb), w0_hi = *reinterpret_cast<const f32x4*>(w0p + 32 * kb + 4);
         f32x4 lo, hi;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            lo[j] = mcg_silu(fmaf(v[6][j], d02, fmaf(v[4][j], d2, v[0][j] + v[2][j])));
-            hi[j] = mcg_silu(fmaf(v[7][j], d02, fmaf(v[5][j], d2, v[1][j] + v[3][j])));
+            lo[j] = mcg_silu(fmaf(w0_lo[j], d02, fmaf(wd_lo[j], d2, v[0][j] + v[2][j])));
+            hi[j] = mcg_silu(fmaf(w0_hi[j], d02, fmaf(wd_hi[j], d2, v[1][j] + v[3][j])));
         }
-        return mcg_pack_bf16(lo, hi);
+#pragma unroll
+        for (int q = 0; q < SPLIT; ++q) {
+            const bf16x8 part = mcg_pack_bf16(lo, hi);
+            a_lds[((half * SPLIT + q) * 4 + wid) * 64 + lane] = part;
+            if (q + 1 < SPLIT) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { lo[j] -= (float)part[j]; hi[j] -= (float)part[4 + j]; }   // exact in fp32
+            }
+        }
     };
-    // one k-block: [barrier] A-operand loads of block kb+1 | MFMAs of block kb | B loads of block kb+2 into the
-    // fragments just consumed | A operand of block kb+1 -> LDS.  sched_barrier pins this order (see mcg_gemm.h).
-    auto block = [&](bf16x8 (&Bc)[NS_T], int kb) {
-        const int buf = kb & 1;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // my A-tile write of the previous block
-        asm volatile("s_barrier" ::: "memory");                      // A(kb) visible; A ring half buf^1 free
-        f32x4 v[8];
-        load_a(kb + 1, v);
-        __builtin_amdgcn_sched_barrier(0);
-        const bf16x8* la = a_lds + buf * 4 * 64 + lane;
-        bf16x8 af[4];
+    // MFMAs of one ring stage: weight part `part` of block kb against activation parts 0 .. SPLIT-1-part
+    auto stage_mfma = [&](const bf16x8 (&Bc)[NS_T], int half, int part) {
+        // A fragments of row tile mt+1 are fetched from LDS while the MFMAs of row tile mt run (pinned: left
+        // alone hipcc hoists all 4 x SPLIT fragment reads to the top of the stage and spills)
+        const int nq = SPLIT - part;
+        bf16x8 af[2][SPLIT];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) af[mt] = la[mt * 64];
+        for (int q = 0; q < SPLIT; ++q)
+            if (q < nq) af[0][q] = a_lds[((half * SPLIT + q) * 4 + 0) * 64 + lane];
 #pragma unroll
-        for (int i = 0; i < NS_T; ++i)
+        for (int mt = 0; mt < 4; ++mt) {
+            if (mt + 1 < 4) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[mt][i] = mcg_mfma_bf16(af[mt], Bc[i], acc[mt][i]);
-        __builtin_amdgcn_sched_barrier(0);
-        load_b(Bc, kb + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        a_lds[((buf ^ 1) * 4 + wid) * 64 + lane] = agen(v);
+                for (int q = 0; q < SPLIT; ++q)
+                    if (q < nq) af[(mt + 1) & 1][q] = a_lds[((half * SPLIT + q) * 4 + mt + 1) * 64 + lane];
+            }
+#pragma unroll
+            for (int q = 0; q < SPLIT; ++q)
+                if (q < nq) {
+#pragma unroll
+                    for (int i = 0; i < NS_T; ++i) acc[mt][i] = mcg_mfma_bf16(af[mt & 1][q], Bc[i], acc[mt][i]);
+                }
+            if (SPLIT > 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // one k-block: [barrier] A-operand loads of block kb+1 | per weight part: MFMAs, then the B loads two stages
+    // ahead into the fragments just consumed | A operand of block kb+1 -> LDS.  sched_barrier pins this order.
+    // `first` = ring slot of the block's first stage (stages alternate slots; SPLIT = 3 flips it every block).
+    auto block = [&](int kb, int first) {
+        const int half = kb & 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // my A-tile writes of the previous block
+        asm volatile("s_barrier" ::: "memory");                      // A(kb) visible; A ring half^1 free
+        f32x4 v[4];
+        if (SPLIT == 1) { load_a(kb + 1, v); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+        for (int part = 0; part < SPLIT; ++part) {
+            const int slot = (first + part) & 1;
+            // (f32x6: the next block's operand inputs are requested behind the first, register-hungriest stage -
+            //  still 84 MFMAs ahead of their use)
+            if (SPLIT > 1 && part == 1) { load_a(kb + 1, v); __builtin_amdgcn_sched_barrier(0); }
+            stage_mfma(Bq[slot], half, part);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(Bq[slot], kb * SPLIT + part + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        agen_store(v, kb + 1 < KB16 ? kb + 1 : KB16 - 1, half ^ 1);
         __builtin_amdgcn_sched_barrier(0);
     };
 
     load_b(Bq[0], 0);
     load_b(Bq[1], 1);
+    __syncthreads();                              // wd | wd0 staged
     {
-        f32x4 v[8];
+        f32x4 v[4];
         load_a(0, v);
-        a_lds[(0 * 4 + wid) * 64 + lane] = agen(v);
+        agen_store(v, 0, 0);
     }
 #pragma unroll 1
     for (int kb = 0; kb < KB16; kb += 2) {        // KB16 = 14 is even
-        block(Bq[0], kb);
-        block(Bq[1], kb + 1);
+        block(kb, 0);
+        block(kb + 1, SPLIT & 1);                 // an odd number of stages per block flips the ring phase
     }
 
     // ---- epilogue
@@ -1200,6 +1256,7 @@ struct EdgeLayer {      // second layer + head of an edge MLP, and its factorise
     float *w2_Bp = nullptr, *b2 = nullptr, *wv = nullptr;
     float bv = 0.f;
     uint16_t *pab_Bp16 = nullptr, *w2_Bp16 = nullptr;     // bf16 operand packs
+    uint16_t* w2_Bp16x3 = nullptr;                        // W2 as three bf16 parts, [k-block][part][nt][lane][8] (f32x6 mode)
 };
 struct NodeLayer {
     float *w3_Bp = nullptr, *b3 = nullptr, *w4_Bp = nullptr, *b4 = nullptr;
@@ -1211,6 +1268,7 @@ struct NodeLayer {
 struct mcg_egnn {
     int n_blocks = 0;
     bool bf16 = false;          // MFMA operands rounded to bf16 (opt-in, mcg_egnn_set_precision)
+    bool x6 = false;            // f32x6: edge second layer as six bf16 partial products of three-part operands (fp32-accurate)
     float *emb_wT = nullptr, *emb_b = nullptr, *out_w = nullptr, *out_b = nullptr;
     std::vector<EdgeLayer> gcl_edge;   // 2 per block
     std::vector<NodeLayer> gcl_node;   // 2 per block
@@ -1290,6 +1348,25 @@ int build_edge_layer(mcg_egnn* m, EdgeLayer& L, const float* w1 /*[420][842]*/, 
         mcg_pack_b16(b16, H, NT, [&](int n, int k) -> float { return n < H ? w2[(size_t)n * H + k] : 0.f; });
         if (int e = upload16(b16, &L.w2_Bp16)) return e;
         m->allocs.push_back(L.w2_Bp16);
+        // f32x6 mode: w = w1 + w2 + w3 with bf16 parts (each the RNE rounding of what the previous ones left),
+        // packed part-major inside every 32-k block
+        const int kb_n = mcg_kblocks16(H);
+        std::vector<uint16_t> x3((size_t)kb_n * 3 * NT * 64 * 8, 0);
+        auto bf_to_f = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; __builtin_memcpy(&f, &u, 4); return f; };
+        for (int kb = 0; kb < kb_n; ++kb)
+            for (int nt = 0; nt < NT; ++nt)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = 32 * kb + 8 * (l >> 4) + j, n = nt * 16 + (l & 15);
+                        float r = (k < H && n < H) ? w2[(size_t)n * H + k] : 0.f;
+                        for (int part = 0; part < 3; ++part) {
+                            const uint16_t hbits = mcg_f32_to_bf16_bits(r);
+                            x3[((((size_t)kb * 3 + part) * NT + nt) * 64 + l) * 8 + j] = hbits;
+                            r -= bf_to_f(hbits);
+                        }
+                    }
+        if (int e = upload16(x3, &L.w2_Bp16x3)) return e;
+        m->allocs.push_back(L.w2_Bp16x3);
     }
     v.assign(HP, 0.f);
     for (int n = 0; n < H; ++n) v[n] = b2[n];
@@ -1354,19 +1431,27 @@ void launch_edge(bool equiv, const EdgeArgs& a, int n_waves, hipStream_t s) {
     else hipLaunchKernelGGL((k_edge<MT, false>), dim3(n_waves), dim3(64), 0, s, a);
 }
 
-int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipStream_t s, bool bf16 = false) {
+int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipStream_t s, bool bf16 = false, bool x6 = false) {
     if (pl->n_waves == 0) return MCG_OK;
     EdgeArgs a;
     a.pab = pl->pab; a.x = pl->x; a.x0 = pl->x0; a.wd = L.wd; a.wd0 = L.wd0; a.Bp = L.w2_Bp; a.b2 = L.b2;
     a.wv = L.wv; a.bv = L.bv; a.n_nodes = pl->n_nodes; a.node_off = pl->node_off; a.row_off = pl->row_off;
     a.B = pl->B; a.tile_mol = pl->tile_mol; a.row_ij = pl->row_ij; a.wave_nf = pl->wave_nf; a.wave_poff = pl->wave_poff;
     a.n_rows = pl->n_rows; a.n_mtiles = pl->n_mtiles; a.n_waves = pl->n_waves; a.P = P;
+    if (x6) {
+        if (pl->MT != 4) { mcg_set_error("f32x6 mode needs an edge_mt = 4 plan"); return MCG_ERR_STATE; }
+        a.Bp = reinterpret_cast<const float*>(L.w2_Bp16x3);
+        if (equiv) hipLaunchKernelGGL((k_edge_bf16_w64<true, 3>), dim3(pl->n_waves), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_edge_bf16_w64<false, 3>), dim3(pl->n_waves), dim3(256), 0, s, a);
+        MCG_HIP(hipGetLastError());
+        return MCG_OK;
+    }
     if (bf16) {
         a.Bp = reinterpret_cast<const float*>(L.w2_Bp16);
         const int wgs = (pl->n_waves + 3) / 4;
         if (pl->MT == 4) {
-            if (equiv) hipLaunchKernelGGL((k_edge_bf16_w64<true>), dim3(pl->n_waves), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((k_edge_bf16_w64<false>), dim3(pl->n_waves), dim3(256), 0, s, a);
+            if (equiv) hipLaunchKernelGGL((k_edge_bf16_w64<true, 1>), dim3(pl->n_waves), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_edge_bf16_w64<false, 1>), dim3(pl->n_waves), dim3(256), 0, s, a);
         } else if (pl->MT == 1) {
             if (equiv) hipLaunchKernelGGL((k_edge_lds_bf16<1, true>), dim3(wgs), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((k_edge_lds_bf16<1, false>), dim3(wgs), dim3(256), 0, s, a);
@@ -1377,7 +1462,7 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
         MCG_HIP(hipGetLastError());
         return MCG_OK;
     }
-    if (pl->MT == 4) { mcg_set_error("edge_mt = 4 plans are for the bf16 mode only"); return MCG_ERR_STATE; }
+    if (pl->MT == 4) { mcg_set_error("edge_mt = 4 plans are for the bf16 / f32x6 modes only"); return MCG_ERR_STATE; }
     // small batches: column-split latency variant (one workgroup per 16-row tile).  Measured per edge launch
     // (tools/bench_small.py): <= 256 tiles 24 us, <= 512 tiles 36 us vs 53 us for the throughput kernel's
     // single 16-row chain; beyond 512 tiles the 4x W2 staging traffic makes it slower (59 us at 527 tiles).
@@ -1416,7 +1501,7 @@ int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s) {
     const bool lp = m->bf16;
     if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
                      MCG_ACT_NONE, s, lp ? E.pab_Bp16 : nullptr)) return e;
-    if (int e = run_edge(pl, E, false, pl->P, s, lp)) return e;
+    if (int e = run_edge(pl, E, false, pl->P, s, lp, m->x6)) return e;
     // (reading the partials directly in the node GEMM's A-loader was tried: the 4-way gather costs the
     //  GEMM as much as the ~6 us combine launch it saves at config 2 and more at config 3)
     if (pl->node_slots)
@@ -1439,7 +1524,7 @@ int run_equiv(const mcg_egnn* m, mcg_plan* pl, int block, hipStream_t s) {
     const int M = pl->M;
     if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
                      MCG_ACT_NONE, s, m->bf16 ? E.pab_Bp16 : nullptr)) return e;
-    if (int e = run_edge(pl, E, true, pl->Px, s, m->bf16)) return e;
+    if (int e = run_edge(pl, E, true, pl->Px, s, m->bf16, m->x6)) return e;
     const int threads = M * 4;
     if (pl->node_slots)
         hipLaunchKernelGGL(k_coord_update_t, dim3((threads + 255) / 256), dim3(256), 0, s, pl->Px, pl->node_slots, M, pl->x);
@@ -1526,7 +1611,9 @@ int mcg_egnn_create(const float* const* tensors, int n_tensors, int hidden, int 
 // (BASELINE.json configs[4]); bf16 = 0 (default): exact fp32 MFMA.
 int mcg_egnn_set_precision(mcg_egnn* m, int bf16) {
     if (!m) return MCG_ERR_ARG;
-    m->bf16 = bf16 != 0;
+    if (bf16 < 0 || bf16 > 2) { mcg_set_error("mcg_egnn_set_precision: mode must be 0 (fp32), 1 (bf16) or 2 (f32x6)"); return MCG_ERR_ARG; }
+    m->bf16 = bf16 == 1;
+    m->x6 = bf16 == 2;
     return MCG_OK;
 }
 
@@ -1777,7 +1864,7 @@ int mcg_egnn_dynamics(const mcg_egnn* m, mcg_plan* pl, const float* t, const flo
         if (out != out_user) MCG_HIP(hipMemcpyAsync(out_user, out, n_xh * sizeof(float), hipMemcpyDeviceToDevice, s));
         return MCG_OK;
     };
-    const void* key[5] = {xh, context, out, m, m->bf16 ? (const void*)1 : nullptr};
+    const void* key[5] = {xh, context, out, m, (const void*)(size_t)(m->bf16 ? 1 : m->x6 ? 2 : 0)};
     if (pl->graph_exec && memcmp(key, pl->g_key, sizeof(key)) == 0) {
         MCG_HIP(hipGraphLaunch(pl->graph_exec, s));
         return finish();
@@ -1827,7 +1914,7 @@ int mcg_bench_edge(const mcg_egnn* m, mcg_plan* pl, int layer, int equiv, int it
     if (!m || !pl || iters < 1 || layer < 0 || layer >= (equiv ? m->n_blocks : 2 * m->n_blocks)) return MCG_ERR_ARG;
     for (int i = 0; i < iters; ++i)
         if (int e = run_edge(pl, equiv ? m->equiv[layer] : m->gcl_edge[layer], equiv != 0, equiv ? pl->Px : pl->P,
-                             (hipStream_t)stream, m->bf16)) return e;
+                             (hipStream_t)stream, m->bf16, m->x6)) return e;
     return MCG_OK;
 }
 

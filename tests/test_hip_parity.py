@@ -717,3 +717,42 @@ def test_evaluate_shape_vs_reference_pipeline():
         assert res[i]["orientation"] == int(g[key][1]), key
     assert res[3]["orientation"] == 0 and abs(res[3]["shape_tanimoto"] - 1.0) < 1e-4      # the reference itself
     assert res[2]["coords"].shape == (10, 3)
+
+
+def test_f32x6_mode_matches_fp32_tolerance(edm_sd):
+    """"f32x6": the edge MLP's 420x420 contraction as six bf16 partial products of three-part operands, fp32
+    accumulate.  It must meet the SAME stated fp32 tolerance against the oracle as the exact-fp32 path, on a
+    ragged batch and on the golden seam vectors, and be deterministic."""
+    from ml_conformer_generator_amd.egnn import EGNNDynamics
+    from oracle import egnn_oracle as EO
+    from oracle import host_oracle as HO
+    d = EGNNDynamics(device=DEV)
+    d.load_reference_state_dict(edm_sd)
+    d.set_precision("f32x6")
+    torch.manual_seed(21)
+    sizes = torch.tensor([19, 27, 15, 33, 39, 22])
+    N = 39
+    nm, em = HO.masks_from_sizes(sizes, N)
+    z = torch.randn(6, N, 11) * nm
+    ctx = torch.randn(6, 1, 3).repeat(1, N, 1) * nm
+    t = torch.full((6, 1), 0.35)
+    out = d(t.to(DEV), z.to(DEV), nm.to(DEV), em.to(DEV), ctx.to(DEV)).cpu()
+    assert next(iter(d._plans.values())).edge_mt == 4
+    ref = EO.egnn_dynamics(edm_sd, t, z, nm, em, ctx)
+    ok, err, sc = close(out, ref)
+    assert ok, (err, sc)
+    out2 = d(t.to(DEV), z.to(DEV), nm.to(DEV), em.to(DEV), ctx.to(DEV)).cpu()
+    assert torch.equal(out, out2)
+    assert float((out * (1 - nm)).abs().max()) == 0.0
+    for tag in ("b2n20", "b3n39"):
+        g = load_golden(f"dynamics_{tag}.npz")
+        o = d(g["t"].to(DEV), g["xh"].to(DEV), g["node_mask"].to(DEV), edge_mask_of(g["node_mask"]).to(DEV),
+              g["context"].to(DEV)).cpu()
+        ok, err, sc = close(o, g["out"])
+        assert ok, (tag, err, sc)
+    d.set_precision("f32")
+    out32 = d(t.to(DEV), z.to(DEV), nm.to(DEV), em.to(DEV), ctx.to(DEV)).cpu()
+    e6 = float((out - ref).abs().max()) / float(ref.abs().max())
+    e32 = float((out32 - ref).abs().max()) / float(ref.abs().max())
+    print(f"max rel err vs oracle: f32x6 {e6:.2e}, exact fp32 {e32:.2e}")
+    assert e6 < 5e-6
