@@ -245,6 +245,8 @@ def main():
         plan = next(reversed(gen.generative_model.dynamics._plans.values()))
         edge_s = time_edge_kernel(gen, plan, dev)
         fl = edge_flops_per_launch(plan.n_real_edges)
+        if args.dtype == "f32x6":
+            fl *= 6.0          # executed bf16 FLOPs: six partial products per fp32 product (K padded 420 -> 448 not counted)
         achieved = fl / edge_s / 1e12
         peak_tf = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else 2500.0      # dense bf16 MFMA peak
         agg_s, agg_b = time_aggregate_kernel(plan, dev)
@@ -276,8 +278,10 @@ def main():
             "config": {"workload": f"{cfg_label}: n_samples={B}/GPU, {args.n_atoms}"
                                    f"{'+-' + str(args.variance) if args.variance else ''} heavy atoms, "
                                    f"diffusion_steps={args.diffusion_steps}, "
-                                   + ("fp32 HIP EGNN + GCN" if args.dtype == "f32" else
-                                      "bf16-operand MFMA HIP EGNN (fp32 accumulate/state) + fp32 GCN"),
+                                   + {"f32": "fp32 HIP EGNN + GCN",
+                                      "bf16": "bf16-operand MFMA HIP EGNN (fp32 accumulate/state) + fp32 GCN",
+                                      "f32x6": "fp32 HIP EGNN with the edge-MLP contraction as 6 bf16 partial products of "
+                                               "3-part fp32 operands (fp32-accurate, fp32 accumulate) + fp32 GCN"}[args.dtype],
                        "parallelism": f"batch-sharded x{world}, RCCL all_gather at end" if world > 1 else "single GPU",
                        "edge_rows_per_wave": 16 * plan.edge_mt, "real_edges": plan.n_real_edges,
                        "real_nodes": plan.n_real_nodes},

@@ -34,9 +34,13 @@ int mcg_abi_version(void);
  * fragment order and uploads them. */
 int mcg_egnn_create(const float* const* tensors_host, int n_tensors, int hidden, int n_blocks, mcg_egnn** out);
 void mcg_egnn_destroy(mcg_egnn* m);
-/* bf16 = 1: the MFMA operands of the EGNN contractions are rounded to bf16 (fp32 accumulate, fp32
- * coordinates / aggregates / epilogues) - BASELINE.json configs[4]; 0 (default) = exact fp32 MFMA. */
-int mcg_egnn_set_precision(mcg_egnn* m, int bf16);
+/* mode 0 (default): exact fp32 MFMA everywhere.
+ * mode 1 "bf16":  the MFMA operands of the EGNN contractions are rounded to bf16 (fp32 accumulate, fp32
+ *                 coordinates / aggregates / epilogues) - BASELINE.json configs[4].
+ * mode 2 "f32x6": fp32-accurate edge-MLP contraction on the bf16 matrix pipe: each fp32 operand is carried as the
+ *                 exact sum of three bf16 parts and the six partial products of weight >= 2^-16 are accumulated
+ *                 in fp32 (dropped terms <= 2^-23 relative); everything else as mode 0.  Needs edge_mt = 4 plans. */
+int mcg_egnn_set_precision(mcg_egnn* m, int mode);
 
 /* ---- Batch plan.  Replaces the per-call `get_adj_matrix` edge-list rebuild (egnn.py:475,515-541)
  * and the node/edge masks (mol_utils.py:226-252): node_mask[b] is the prefix of n_nodes_host[b]

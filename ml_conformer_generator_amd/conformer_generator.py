@@ -68,7 +68,7 @@ class MLConformerGenerator(torch.nn.Module):
         adj_mat_seer = AdjMatSeer(dimension=dimension, n_hidden=2048, embedding_dim=64, num_embeddings=36,
                                   num_bond_types=num_bond_types, device=device)
         generative_model.load_state_dict(_load_state_dict(edm_weights, device))
-        net_dynamics.set_precision(compute_dtype)      # "bf16": opt-in reduced-precision MFMA operands
+        net_dynamics.set_precision(compute_dtype)      # opt-in: "bf16" reduced-precision operands, "f32x6" split-operand fp32
         adj_mat_seer.load_state_dict(_load_state_dict(adj_mat_seer_weights, device))
         # re-wire the schedule to the requested number of steps (conformer_generator.py:105-113)
         generative_model.gamma = PredefinedNoiseSchedule(timesteps=diffusion_steps, precision=NOISE_PRECISION)

@@ -115,7 +115,8 @@ class EGNNDynamics(torch.nn.Module):
 
     def set_precision(self, compute_dtype: str = "f32") -> None:
         """"f32" (default): exact fp32 MFMA.  "bf16": MFMA operands rounded to bf16, fp32 accumulate,
-        fp32 coordinates/aggregates/epilogues (BASELINE.json configs[4])."""
+        fp32 coordinates/aggregates/epilogues (BASELINE.json configs[4]).  "f32x6": fp32-accurate edge-MLP
+        contraction as six bf16 partial products of three-part fp32 operands (see include/mlconfgen_hip.h)."""
         if compute_dtype not in ("f32", "bf16", "f32x6"):
             raise ValueError("compute_dtype must be 'f32', 'bf16' or 'f32x6'")
         _lib.check(_lib.lib().mcg_egnn_set_precision(self.handle, {"f32": 0, "bf16": 1, "f32x6": 2}[compute_dtype]),
