@@ -205,6 +205,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = ""        # the version banner goes to stdout, where only the JSON line belongs
         # MCG_DIST_BACKEND=gloo: dry run of the N > 1 control flow with several ranks on ONE GPU
         backend = os.environ.get("MCG_DIST_BACKEND", "nccl")
         dev_index = local_rank % max(1, torch.cuda.device_count())
@@ -351,10 +353,20 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, sd, gsd)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        line = json.dumps(out)
+    else:
+        line = None
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        # the JSON line is the LAST thing on stdout: RCCL writes its banner / warnings through C stdio
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
