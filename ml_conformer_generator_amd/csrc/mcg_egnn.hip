@@ -1438,8 +1438,7 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
     a.wv = L.wv; a.bv = L.bv; a.n_nodes = pl->n_nodes; a.node_off = pl->node_off; a.row_off = pl->row_off;
     a.B = pl->B; a.tile_mol = pl->tile_mol; a.row_ij = pl->row_ij; a.wave_nf = pl->wave_nf; a.wave_poff = pl->wave_poff;
     a.n_rows = pl->n_rows; a.n_mtiles = pl->n_mtiles; a.n_waves = pl->n_waves; a.P = P;
-    if (x6) {
-        if (pl->MT != 4) { mcg_set_error("f32x6 mode needs an edge_mt = 4 plan"); return MCG_ERR_STATE; }
+    if (x6 && pl->MT == 4) {       // (plans with 16/32-row tiles - molecules below 6 atoms - run the exact fp32 kernels)
         a.Bp = reinterpret_cast<const float*>(L.w2_Bp16x3);
         if (equiv) hipLaunchKernelGGL((k_edge_bf16_w64<true, 3>), dim3(pl->n_waves), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_edge_bf16_w64<false, 3>), dim3(pl->n_waves), dim3(256), 0, s, a);

@@ -159,6 +159,17 @@ def test_small_fragments_and_degenerate_sizes(dyn, edm_sd):
     out = dyn(t.to(DEV), z.to(DEV), nm.to(DEV), em.to(DEV), ctx.to(DEV))
     ok, err, sc = close(out, ref)
     assert ok, f"err {err} scale {sc}"
+    # the opt-in operand modes keep working on such batches (their 64-row kernel needs >= 6 atoms per molecule:
+    # bf16 falls back to its 16-row kernel, f32x6 to the exact fp32 kernels)
+    from ml_conformer_generator_amd.egnn import EGNNDynamics
+    d2 = EGNNDynamics(device=DEV)
+    d2.load_reference_state_dict(edm_sd)
+    d2.set_precision("f32x6")
+    ok, err, sc = close(d2(t.to(DEV), z.to(DEV), nm.to(DEV), em.to(DEV), ctx.to(DEV)), ref)
+    assert ok, f"f32x6 err {err} scale {sc}"
+    d2.set_precision("bf16")
+    o16 = d2(t.to(DEV), z.to(DEV), nm.to(DEV), em.to(DEV), ctx.to(DEV)).cpu()
+    assert float((o16 - ref).abs().max()) / float(ref.abs().max()) < 3e-2
 
 
 def test_non_prefix_mask_rejected(dyn):
