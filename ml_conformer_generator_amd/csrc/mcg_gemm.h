@@ -146,14 +146,22 @@ __global__ __launch_bounds__(256) void mcg_gemm_bf16_kernel(McgGemmArgs p) {
         // 3-deep register ring, same discipline as the fp32 kernel (pinned order, unconditional loads)
         f32x4 Ar[3][2][2];
         bf16x8 Br[3][RN];
+        const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, 0xffffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8*>(bseg), 0, 0xffffffff, 0x00020000);
+        const unsigned oa0 = (unsigned)(rA[0] * lda + 8 * g) * 4u, oa1 = (unsigned)(rA[1] * lda + 8 * g) * 4u;
+        unsigned obn[RN];
+#pragma unroll
+        for (int n = 0; n < RN; ++n) obn[n] = (unsigned)((nt0 + ncl[n]) * 64 + lane) * 16u;
+        const int bbytes = p.n_tiles * 64 * 16;
+        auto ld = [](const __amdgpu_buffer_rsrc_t& r, unsigned v, int so) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)v, so, 0); };
         auto load_block = [&](int slot, int kb) {
             kb = kb < blocks ? kb : blocks - 1;
-            Ar[slot][0][0] = *reinterpret_cast<const f32x4*>(a0 + 32 * kb);
-            Ar[slot][0][1] = *reinterpret_cast<const f32x4*>(a0 + 32 * kb + 4);
-            Ar[slot][1][0] = *reinterpret_cast<const f32x4*>(a1 + 32 * kb);
-            Ar[slot][1][1] = *reinterpret_cast<const f32x4*>(a1 + 32 * kb + 4);
+            Ar[slot][0][0] = __builtin_bit_cast(f32x4, ld(rs_a, oa0, 128 * kb));
+            Ar[slot][0][1] = __builtin_bit_cast(f32x4, ld(rs_a, oa0, 128 * kb + 16));
+            Ar[slot][1][0] = __builtin_bit_cast(f32x4, ld(rs_a, oa1, 128 * kb));
+            Ar[slot][1][1] = __builtin_bit_cast(f32x4, ld(rs_a, oa1, 128 * kb + 16));
 #pragma unroll
-            for (int n = 0; n < RN; ++n) Br[slot][n] = bq[(size_t)kb * bstride + ncl[n] * 64];
+            for (int n = 0; n < RN; ++n) Br[slot][n] = __builtin_bit_cast(bf16x8, ld(rs_b, obn[n], kb * bbytes));
         };
         auto compute = [&](int slot) {
             const bf16x8 A0 = mcg_pack_bf16(Ar[slot][0][0], Ar[slot][0][1]);
@@ -279,13 +287,23 @@ __global__ __launch_bounds__(256) void mcg_gemm_kernel(McgGemmArgs p) {
         f32x4 Ar[RING][2], Br[RING][RN];
         // loads are UNCONDITIONAL (group index and column tile clamped): a runtime "load or zero"
         // select makes hipcc branch around every load and drain vmcnt(0) behind it.
+        // operand addresses = buffer descriptor (SGPRs) + one 32-bit lane offset + a scalar group offset: with
+        // 64-bit per-lane pointers every load of the loop costs a 64-bit VALU add, and on gfx950 VALU issue time
+        // adds to fp32-MFMA time
+        const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, 0xffffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bseg), 0, 0xffffffff, 0x00020000);
+        const unsigned oa0 = (unsigned)(rA[0] * lda + 4 * g) * 4u, oa1 = (unsigned)(rA[1] * lda + 4 * g) * 4u;
+        unsigned obn[RN];
+#pragma unroll
+        for (int n = 0; n < RN; ++n) obn[n] = (unsigned)((nt0 + ncl[n]) * 256 + lane * 4) * 4u;
+        const int gbytes = p.n_tiles * 256 * 4;
         auto load_group = [&](int slot, int q) {
             q = q < groups ? q : groups - 1;
-            Ar[slot][0] = *reinterpret_cast<const f32x4*>(a0 + 16 * q);
-            Ar[slot][1] = *reinterpret_cast<const f32x4*>(a1 + 16 * q);
+            Ar[slot][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)oa0, 64 * q, 0));
+            Ar[slot][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)oa1, 64 * q, 0));
 #pragma unroll
             for (int n = 0; n < RN; ++n)
-                Br[slot][n] = *reinterpret_cast<const f32x4*>(bq + (size_t)q * gstride + ncl[n] * 256);
+                Br[slot][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)obn[n], q * gbytes, 0));
         };
         auto compute = [&](int slot) {
 #pragma unroll
@@ -378,7 +396,7 @@ static inline hipError_t mcg_gemm_launch(const McgGemmArgs& a, hipStream_t s, bo
             if (best < 0 || cost <= best) { best = cost; rn = cand; }
         }
     } else {
-        static const double u1[4] = {0, 3.7, 5.0, 8.9}, uinf[4] = {0, 5.8, 10.4, 21.9};
+        static const double u1[4] = {0, 3.4, 5.2, 9.0}, uinf[4] = {0, 4.8, 8.0, 12.5};
         double best = -1;
         for (int cand = 1; cand <= 3; ++cand) {
             const double r = (double)rowblocks * ((a.n_tiles + cand - 1) / cand) / 1024.0;
