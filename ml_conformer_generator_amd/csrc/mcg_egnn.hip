@@ -335,15 +335,20 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const float* pa[MT];
-    const float* pb[MT];
+    // operand addresses: buffer descriptor + 32-bit lane offset + scalar group offset (no 64-bit VALU adds per load)
+    const __amdgpu_buffer_rsrc_t rs_pab = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pab), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wd), 0, (HP + 32) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wd0), 0, (HP + 32) * 4, 0x00020000);
+    unsigned oa[MT], ob[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        pa[mt] = p.pab + (size_t)R.ni[mt] * (2 * HP) + 4 * g;
-        pb[mt] = p.pab + (size_t)R.nj[mt] * (2 * HP) + HP + 4 * g;
+        oa[mt] = (unsigned)(R.ni[mt] * (2 * HP) + 4 * g) * 4u;
+        ob[mt] = (unsigned)(R.nj[mt] * (2 * HP) + HP + 4 * g) * 4u;
     }
-    const float* wdp = p.wd + 4 * g;
-    const float* w0p = p.wd0 + 4 * g;
+    const unsigned ow = (unsigned)(4 * g) * 4u;
+    auto ld4 = [](const __amdgpu_buffer_rsrc_t& r, unsigned v, int so) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)v, so, 0));
+    };
 
     // stage group q of the B-pack into LDS buffer `buf`: 7 x 1 KiB pieces per wave.  MUBUF
     // (buffer_load ... lds) rather than global_load_lds: hipcc treats the latter as a FLAT access
@@ -383,11 +388,11 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
         f32x4 va[MT], vb[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            va[mt] = *reinterpret_cast<const f32x4*>(pa[mt]);
-            vb[mt] = *reinterpret_cast<const f32x4*>(pb[mt]);
+            va[mt] = ld4(rs_pab, oa[mt], 0);
+            vb[mt] = ld4(rs_pab, ob[mt], 0);
         }
-        const f32x4 wdv = *reinterpret_cast<const f32x4*>(wdp);
-        const f32x4 w0v = *reinterpret_cast<const f32x4*>(w0p);
+        const f32x4 wdv = ld4(rs_wd, ow, 0);
+        const f32x4 w0v = ld4(rs_w0, ow, 0);
         agen(va, vb, wdv, w0v, a4);
     }
 
@@ -411,11 +416,11 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
         if (q + 1 < NG) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                va[mt] = *reinterpret_cast<const f32x4*>(pa[mt] + 16 * (q + 1));
-                vb[mt] = *reinterpret_cast<const f32x4*>(pb[mt] + 16 * (q + 1));
+                va[mt] = ld4(rs_pab, oa[mt], 64 * (q + 1));
+                vb[mt] = ld4(rs_pab, ob[mt], 64 * (q + 1));
             }
-            wdv = *reinterpret_cast<const f32x4*>(wdp + 16 * (q + 1));
-            w0v = *reinterpret_cast<const f32x4*>(w0p + 16 * (q + 1));
+            wdv = ld4(rs_wd, ow, 64 * (q + 1));
+            w0v = ld4(rs_w0, ow, 64 * (q + 1));
         } else {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
