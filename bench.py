@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-phi-calls", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32x6"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32x6", "f32x9"],
                     help="bf16 = opt-in reduced-precision MFMA operands (configs[4]); the default bench line is fp32")
     ap.add_argument("--no-x6-probe", action="store_true",
                     help="skip the extra (untimed-for-`value`) pass in the opt-in f32x6 mode that is reported beside the fp32 line")
@@ -293,8 +293,8 @@ def main():
         plan = next(reversed(gen.generative_model.dynamics._plans.values()))
         edge_s = time_edge_kernel(gen, plan, dev)
         fl = edge_flops_per_launch(plan.n_real_edges)
-        if args.dtype == "f32x6":
-            fl *= 6.0          # executed bf16 FLOPs: six partial products per fp32 product (K padded 420 -> 448 not counted)
+        if args.dtype in ("f32x6", "f32x9"):
+            fl *= 6.0 if args.dtype == "f32x6" else 9.0          # executed bf16 FLOPs: six partial products per fp32 product (K padded 420 -> 448 not counted)
         achieved = fl / edge_s / 1e12
         peak_tf = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else 2500.0      # dense bf16 MFMA peak
         agg_s, agg_b = time_aggregate_kernel(plan, dev)
@@ -329,7 +329,9 @@ def main():
                                    + {"f32": "fp32 HIP EGNN + GCN",
                                       "bf16": "bf16-operand MFMA HIP EGNN (fp32 accumulate/state) + fp32 GCN",
                                       "f32x6": "fp32 HIP EGNN with the edge-MLP contraction as 6 bf16 partial products of "
-                                               "3-part fp32 operands (fp32-accurate, fp32 accumulate) + fp32 GCN"}[args.dtype],
+                                               "3-part fp32 operands (fp32-accurate, fp32 accumulate) + fp32 GCN",
+                                      "f32x9": "fp32 HIP EGNN with the edge-MLP contraction as all 9 bf16 partial products of "
+                                               "3-part fp32 operands (exact products, fp32 accumulate) + fp32 GCN"}[args.dtype],
                        "parallelism": f"batch-sharded x{world}, RCCL all_gather at end" if world > 1 else "single GPU",
                        "edge_rows_per_wave": 16 * plan.edge_mt, "real_edges": plan.n_real_edges,
                        "real_nodes": plan.n_real_nodes},

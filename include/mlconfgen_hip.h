@@ -39,7 +39,9 @@ void mcg_egnn_destroy(mcg_egnn* m);
  *                 coordinates / aggregates / epilogues) - BASELINE.json configs[4].
  * mode 2 "f32x6": fp32-accurate edge-MLP contraction on the bf16 matrix pipe: each fp32 operand is carried as the
  *                 exact sum of three bf16 parts and the six partial products of weight >= 2^-16 are accumulated
- *                 in fp32 (dropped terms <= 2^-23 relative); everything else as mode 0.  Needs edge_mt = 4 plans. */
+ *                 in fp32 (dropped terms <= 2^-23 relative); everything else as mode 0.  Uses edge_mt = 4 plans
+ *                 (other plans run the exact kernels).
+ * mode 3 "f32x9": as mode 2 with all nine partial products (every fp32 product formed exactly). */
 int mcg_egnn_set_precision(mcg_egnn* m, int mode);
 
 /* ---- Batch plan.  Replaces the per-call `get_adj_matrix` edge-list rebuild (egnn.py:475,515-541)

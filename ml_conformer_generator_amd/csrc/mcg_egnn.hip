@@ -843,7 +843,7 @@ template <int SPLIT> constexpr int w64_lds_floats() { return 2 * HP + 2 * W64_KP
 // in fp32: the dropped terms are <= 2^-23 relative, i.e. the contraction is fp32-accurate, on a matrix pipe that is
 // 16x faster per k than v_mfma_f32_16x16x4_f32 (6/16 of the exact kernel's matrix time).  The weight parts are
 // streamed part-major per 32-k block (stage = kb*3 + part); part p meets the activation parts 0 .. 2-p.
-template <bool EQUIV, int SPLIT>
+template <bool EQUIV, int SPLIT, bool FULL = false>      // FULL: all SPLIT^2 partial products ("f32x9": nothing dropped)
 __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
     __shared__ __attribute__((aligned(16))) float lds[w64_lds_floats<SPLIT>()];
     float* const par = lds;                                              // b2 | wv
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
     auto stage_mfma = [&](const bf16x8 (&Bc)[NS_T], int half, int part) {
         // A fragments of row tile mt+1 are fetched from LDS while the MFMAs of row tile mt run (pinned: left
         // alone hipcc hoists all 4 x SPLIT fragment reads to the top of the stage and spills)
-        const int nq = SPLIT - part;
+        const int nq = FULL ? SPLIT : SPLIT - part;
         bf16x8 af[2][SPLIT];
 #pragma unroll
         for (int q = 0; q < SPLIT; ++q)
@@ -1273,7 +1273,8 @@ struct NodeLayer {
 struct mcg_egnn {
     int n_blocks = 0;
     bool bf16 = false;          // MFMA operands rounded to bf16 (opt-in, mcg_egnn_set_precision)
-    bool x6 = false;            // f32x6: edge second layer as six bf16 partial products of three-part operands (fp32-accurate)
+    int x6 = 0;                 // 1 = f32x6: edge second layer as six bf16 partial products of three-part operands
+                                // (fp32-accurate); 2 = f32x9: all nine products (nothing dropped)
     float *emb_wT = nullptr, *emb_b = nullptr, *out_w = nullptr, *out_b = nullptr;
     std::vector<EdgeLayer> gcl_edge;   // 2 per block
     std::vector<NodeLayer> gcl_node;   // 2 per block
@@ -1436,7 +1437,7 @@ void launch_edge(bool equiv, const EdgeArgs& a, int n_waves, hipStream_t s) {
     else hipLaunchKernelGGL((k_edge<MT, false>), dim3(n_waves), dim3(64), 0, s, a);
 }
 
-int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipStream_t s, bool bf16 = false, bool x6 = false) {
+int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipStream_t s, bool bf16 = false, int x6 = 0) {
     if (pl->n_waves == 0) return MCG_OK;
     EdgeArgs a;
     a.pab = pl->pab; a.x = pl->x; a.x0 = pl->x0; a.wd = L.wd; a.wd0 = L.wd0; a.Bp = L.w2_Bp; a.b2 = L.b2;
@@ -1445,8 +1446,13 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
     a.n_rows = pl->n_rows; a.n_mtiles = pl->n_mtiles; a.n_waves = pl->n_waves; a.P = P;
     if (x6 && pl->MT == 4) {       // (plans with 16/32-row tiles - molecules below 6 atoms - run the exact fp32 kernels)
         a.Bp = reinterpret_cast<const float*>(L.w2_Bp16x3);
-        if (equiv) hipLaunchKernelGGL((k_edge_bf16_w64<true, 3>), dim3(pl->n_waves), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_edge_bf16_w64<false, 3>), dim3(pl->n_waves), dim3(256), 0, s, a);
+        if (x6 == 2) {          // all nine partial products
+            if (equiv) hipLaunchKernelGGL((k_edge_bf16_w64<true, 3, true>), dim3(pl->n_waves), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_edge_bf16_w64<false, 3, true>), dim3(pl->n_waves), dim3(256), 0, s, a);
+        } else {
+            if (equiv) hipLaunchKernelGGL((k_edge_bf16_w64<true, 3>), dim3(pl->n_waves), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_edge_bf16_w64<false, 3>), dim3(pl->n_waves), dim3(256), 0, s, a);
+        }
         MCG_HIP(hipGetLastError());
         return MCG_OK;
     }
@@ -1615,9 +1621,9 @@ int mcg_egnn_create(const float* const* tensors, int n_tensors, int hidden, int 
 // (BASELINE.json configs[4]); bf16 = 0 (default): exact fp32 MFMA.
 int mcg_egnn_set_precision(mcg_egnn* m, int bf16) {
     if (!m) return MCG_ERR_ARG;
-    if (bf16 < 0 || bf16 > 2) { mcg_set_error("mcg_egnn_set_precision: mode must be 0 (fp32), 1 (bf16) or 2 (f32x6)"); return MCG_ERR_ARG; }
+    if (bf16 < 0 || bf16 > 3) { mcg_set_error("mcg_egnn_set_precision: mode must be 0 (fp32), 1 (bf16), 2 (f32x6) or 3 (f32x9)"); return MCG_ERR_ARG; }
     m->bf16 = bf16 == 1;
-    m->x6 = bf16 == 2;
+    m->x6 = bf16 >= 2 ? bf16 - 1 : 0;
     return MCG_OK;
 }
 
@@ -1868,7 +1874,7 @@ int mcg_egnn_dynamics(const mcg_egnn* m, mcg_plan* pl, const float* t, const flo
         if (out != out_user) MCG_HIP(hipMemcpyAsync(out_user, out, n_xh * sizeof(float), hipMemcpyDeviceToDevice, s));
         return MCG_OK;
     };
-    const void* key[5] = {xh, context, out, m, (const void*)(size_t)(m->bf16 ? 1 : m->x6 ? 2 : 0)};
+    const void* key[5] = {xh, context, out, m, (const void*)(size_t)(m->bf16 ? 1 : m->x6 ? 1 + m->x6 : 0)};
     if (pl->graph_exec && memcmp(key, pl->g_key, sizeof(key)) == 0) {
         MCG_HIP(hipGraphLaunch(pl->graph_exec, s));
         return finish();

@@ -117,9 +117,9 @@ class EGNNDynamics(torch.nn.Module):
         """"f32" (default): exact fp32 MFMA.  "bf16": MFMA operands rounded to bf16, fp32 accumulate,
         fp32 coordinates/aggregates/epilogues (BASELINE.json configs[4]).  "f32x6": fp32-accurate edge-MLP
         contraction as six bf16 partial products of three-part fp32 operands (see include/mlconfgen_hip.h)."""
-        if compute_dtype not in ("f32", "bf16", "f32x6"):
-            raise ValueError("compute_dtype must be 'f32', 'bf16' or 'f32x6'")
-        _lib.check(_lib.lib().mcg_egnn_set_precision(self.handle, {"f32": 0, "bf16": 1, "f32x6": 2}[compute_dtype]),
+        if compute_dtype not in ("f32", "bf16", "f32x6", "f32x9"):
+            raise ValueError("compute_dtype must be 'f32', 'bf16', 'f32x6' or 'f32x9'")
+        _lib.check(_lib.lib().mcg_egnn_set_precision(self.handle, {"f32": 0, "bf16": 1, "f32x6": 2, "f32x9": 3}[compute_dtype]),
                    "mcg_egnn_set_precision")
         if compute_dtype != self.compute_dtype:
             self._plans.clear()          # tilings differ between the precisions
@@ -127,7 +127,7 @@ class EGNNDynamics(torch.nn.Module):
 
     # -- plans --------------------------------------------------------------------
     def plan(self, n_nodes: torch.Tensor, max_n_nodes: int, edge_mt: int = 0) -> BatchPlan:
-        if edge_mt == 0 and self.compute_dtype in ("bf16", "f32x6") and int(n_nodes.min()) >= 6:
+        if edge_mt == 0 and self.compute_dtype in ("bf16", "f32x6", "f32x9") and int(n_nodes.min()) >= 6:
             edge_mt = 4          # 64-row workgroup tiles (needs <= 16 nodes per 64 edge rows)
         key = (int(max_n_nodes), int(edge_mt), tuple(int(v) for v in n_nodes.reshape(-1).tolist()))
         p = self._plans.get(key)
