@@ -770,3 +770,39 @@ def test_f32x6_mode_matches_fp32_tolerance(edm_sd):
     e9 = float((out9 - ref).abs().max()) / float(ref.abs().max())
     print(f"max rel err vs oracle: f32x6 {e6:.2e}, f32x9 {e9:.2e}, exact fp32 {e32:.2e}")
     assert e6 < 5e-6 and e9 < 5e-6
+
+
+def test_split_operand_modes_are_as_accurate_as_fp32_against_fp64(edm_sd):
+    """Ground truth = the oracle evaluated in fp64 (weights and inputs are exactly representable, so this is the
+    real-number value of the network up to 1e-16).  The exact-fp32 kernel, f32x9 and f32x6 must sit at the same
+    distance from it as the fp32 CPU evaluation does - i.e. the split-operand modes lose nothing measurable - while
+    the bf16 mode is two orders of magnitude further away."""
+    from ml_conformer_generator_amd.egnn import EGNNDynamics
+    from oracle import egnn_oracle as EO
+    from oracle import host_oracle as HO
+    sd64 = {k: v.double() for k, v in edm_sd.items()}
+    torch.manual_seed(21)
+    sizes = torch.randint(15, 40, (12,))
+    N = 39
+    nm, em = HO.masks_from_sizes(sizes, N)
+    z = torch.randn(12, N, 11) * nm
+    ctx = torch.randn(12, 1, 3).repeat(1, N, 1) * nm
+    t = torch.full((12, 1), 0.35)
+    ref64 = EO.egnn_dynamics(sd64, t.double(), z.double(), nm.double(), em.double(), ctx.double())
+    ref32 = EO.egnn_dynamics(edm_sd, t, z, nm, em, ctx)
+    sc = float(ref64.abs().max())
+
+    def rms(o):
+        return float((o.double() - ref64).pow(2).mean().sqrt()) / sc
+
+    base = rms(ref32)
+    d = EGNNDynamics(device=DEV)
+    d.load_reference_state_dict(edm_sd)
+    got = {}
+    for mode in ("f32", "f32x9", "f32x6", "bf16"):
+        d.set_precision(mode)
+        got[mode] = rms(d(t.to(DEV), z.to(DEV), nm.to(DEV), em.to(DEV), ctx.to(DEV)).cpu())
+    print("rms deviation from fp64 / max|out|: fp32 CPU %.2e, " % base + ", ".join(f"{k} {v:.2e}" for k, v in got.items()))
+    assert got["f32"] < 1.5 * base and got["f32x9"] < 1.5 * base and got["f32x6"] < 1.5 * base
+    assert abs(got["f32x6"] - got["f32"]) < 0.2 * got["f32"]
+    assert got["bf16"] > 20 * got["f32"]
