@@ -1262,10 +1262,12 @@ struct EdgeLayer {      // second layer + head of an edge MLP, and its factorise
     float bv = 0.f;
     uint16_t *pab_Bp16 = nullptr, *w2_Bp16 = nullptr;     // bf16 operand packs
     uint16_t* w2_Bp16x3 = nullptr;                        // W2 as three bf16 parts, [k-block][part][nt][lane][8] (f32x6 mode)
+    uint16_t* pab_Bp16x3 = nullptr;                       // first-layer weights, same three-part form
 };
 struct NodeLayer {
     float *w3_Bp = nullptr, *b3 = nullptr, *w4_Bp = nullptr, *b4 = nullptr;
     uint16_t *w3_Bp16 = nullptr, *w4_Bp16 = nullptr;
+    uint16_t *w3_Bp16x3 = nullptr, *w4_Bp16x3 = nullptr;  // three-part packs for the f32x6 GEMM
 };
 
 }  // namespace
@@ -1351,6 +1353,14 @@ int build_edge_layer(mcg_egnn* m, EdgeLayer& L, const float* w1 /*[420][842]*/, 
         if (int e = upload16(b16, &L.pab_Bp16)) return e;
         m->allocs.push_back(L.pab_Bp16);
         b16.clear();
+        mcg_pack_b16x3(b16, H, 2 * NT, [&](int n, int k) -> float {
+            if (n < HP) return n < H ? w1[(size_t)n * (2 * H + 2) + k] : 0.f;
+            const int nn = n - HP;
+            return nn < H ? w1[(size_t)nn * (2 * H + 2) + H + k] : 0.f;
+        });
+        if (int e = upload16(b16, &L.pab_Bp16x3)) return e;
+        m->allocs.push_back(L.pab_Bp16x3);
+        b16.clear();
         mcg_pack_b16(b16, H, NT, [&](int n, int k) -> float { return n < H ? w2[(size_t)n * H + k] : 0.f; });
         if (int e = upload16(b16, &L.w2_Bp16)) return e;
         m->allocs.push_back(L.w2_Bp16);
@@ -1412,6 +1422,15 @@ int build_node_layer(mcg_egnn* m, NodeLayer& L, const float* w3 /*[420][840]*/, 
         mcg_pack_b16(b16, H, NT, [&](int n, int k) -> float { return n < H ? w4[(size_t)n * H + k] : 0.f; });
         if (int e = upload16(b16, &L.w4_Bp16)) return e;
         m->allocs.push_back(L.w4_Bp16);
+        b16.clear();
+        mcg_pack_b16x3(b16, H, NT, [&](int n, int k) -> float { return n < H ? w3[(size_t)n * (2 * H) + k] : 0.f; });
+        mcg_pack_b16x3(b16, H, NT, [&](int n, int k) -> float { return n < H ? w3[(size_t)n * (2 * H) + H + k] : 0.f; });
+        if (int e = upload16(b16, &L.w3_Bp16x3)) return e;
+        m->allocs.push_back(L.w3_Bp16x3);
+        b16.clear();
+        mcg_pack_b16x3(b16, H, NT, [&](int n, int k) -> float { return n < H ? w4[(size_t)n * H + k] : 0.f; });
+        if (int e = upload16(b16, &L.w4_Bp16x3)) return e;
+        m->allocs.push_back(L.w4_Bp16x3);
     }
     for (int n = 0; n < H; ++n) v[n] = b4[n];
     if (int e = upload(v, &L.b4)) return e;
@@ -1420,6 +1439,13 @@ int build_node_layer(mcg_egnn* m, NodeLayer& L, const float* w3 /*[420][840]*/, 
 }
 
 int g_edge_variant = -1;   // 0: v1 (direct global B), 1: v2 (LDS-staged B); env MCG_EDGE_KERNEL
+
+// f32x6 / f32x9 modes: node-side GEMMs on the split-operand kernel too (MCG_X6_GEMM=0: exact fp32 GEMMs)
+static bool g_x6_gemm() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MCG_X6_GEMM"); v = (e && atoi(e) == 0) ? 0 : 1; }
+    return v != 0;
+}
 
 template <int MT>
 void launch_edge(bool equiv, const EdgeArgs& a, int n_waves, hipStream_t s) {
@@ -1494,10 +1520,15 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
 
 int gemm(const float* A1, int lda1, int K1, const float* A2, int lda2, int K2, const float* Bp, const float* bias,
          const float* resid, int ldr, float* C, int ldc, int M, int n_tiles, int n_store, int act, hipStream_t s,
-         const uint16_t* Bp16 = nullptr) {
+         const uint16_t* Bp16 = nullptr, const uint16_t* Bp16x3 = nullptr) {
     McgGemmArgs g;
     g.A1 = A1; g.lda1 = lda1; g.K1 = K1; g.A2 = A2; g.lda2 = lda2; g.K2 = K2; g.Bp = Bp; g.bias = bias;
     g.resid = resid; g.ldr = ldr; g.C = C; g.ldc = ldc; g.M = M; g.n_tiles = n_tiles; g.n_store = n_store; g.act = act;
+    if (Bp16x3) {            // f32x6: three-part operands on the bf16 pipe, fp32-accurate
+        g.Bp = reinterpret_cast<const float*>(Bp16x3);
+        MCG_HIP(mcg_gemm_x6_launch(g, s));
+        return MCG_OK;
+    }
     if (Bp16) g.Bp = reinterpret_cast<const float*>(Bp16);
     MCG_HIP(mcg_gemm_launch(g, s, Bp16 != nullptr));
     return MCG_OK;
@@ -1509,8 +1540,9 @@ int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s) {
     const NodeLayer& Nl = m->gcl_node[layer];
     const int M = pl->M;
     const bool lp = m->bf16;
+    const bool x6g = m->x6 != 0 && g_x6_gemm();
     if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
-                     MCG_ACT_NONE, s, lp ? E.pab_Bp16 : nullptr)) return e;
+                     MCG_ACT_NONE, s, lp ? E.pab_Bp16 : nullptr, x6g ? E.pab_Bp16x3 : nullptr)) return e;
     if (int e = run_edge(pl, E, false, pl->P, s, lp, m->x6)) return e;
     // (reading the partials directly in the node GEMM's A-loader was tried: the 4-way gather costs the
     //  GEMM as much as the ~6 us combine launch it saves at config 2 and more at config 3)
@@ -1522,9 +1554,9 @@ int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s) {
     MCG_HIP(hipGetLastError());
     // node_mlp: h + W4 silu(W3 [h | agg] + b3) + b4   (egnn.py:30-34,66-67)
     if (int e = gemm(pl->h, HP, H, pl->agg, HP, H, Nl.w3_Bp, Nl.b3, nullptr, 0, pl->t1, HP, M, NT, HP, MCG_ACT_SILU, s,
-                     lp ? Nl.w3_Bp16 : nullptr)) return e;
+                     lp ? Nl.w3_Bp16 : nullptr, x6g ? Nl.w3_Bp16x3 : nullptr)) return e;
     if (int e = gemm(pl->t1, HP, H, nullptr, 0, 0, Nl.w4_Bp, Nl.b4, pl->h, HP, pl->h2, HP, M, NT, HP, MCG_ACT_NONE, s,
-                     lp ? Nl.w4_Bp16 : nullptr)) return e;
+                     lp ? Nl.w4_Bp16 : nullptr, x6g ? Nl.w4_Bp16x3 : nullptr)) return e;
     std::swap(pl->h, pl->h2);
     return MCG_OK;
 }
@@ -1533,7 +1565,7 @@ int run_equiv(const mcg_egnn* m, mcg_plan* pl, int block, hipStream_t s) {
     const EdgeLayer& E = m->equiv[block];
     const int M = pl->M;
     if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
-                     MCG_ACT_NONE, s, m->bf16 ? E.pab_Bp16 : nullptr)) return e;
+                     MCG_ACT_NONE, s, m->bf16 ? E.pab_Bp16 : nullptr, (m->x6 != 0 && g_x6_gemm()) ? E.pab_Bp16x3 : nullptr)) return e;
     if (int e = run_edge(pl, E, true, pl->Px, s, m->bf16, m->x6)) return e;
     const int threads = M * 4;
     if (pl->node_slots)

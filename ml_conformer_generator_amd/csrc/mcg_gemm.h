@@ -214,6 +214,211 @@ __global__ __launch_bounds__(256) void mcg_gemm_bf16_kernel(McgGemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// "f32x6" variant: fp32-accurate GEMM on the bf16 matrix pipe (see k_edge_bf16_w64 in mcg_egnn.hip).  Every fp32
+// operand is the exact sum of three bf16 parts; the six partial products of weight >= 2^-16 are accumulated in fp32.
+// The weights come pre-split ("B-pack16x3": [k-block][part][n-tile][lane][8], host side below).  The activation
+// rows are split ONCE per workgroup: the four waves (which share the same 32 rows) each load and split a quarter
+// of the 32 x 32 block and publish the parts as MFMA fragments through LDS - one barrier per 32-k block.
+template <class F>
+static void mcg_pack_b16x3(std::vector<uint16_t>& dst, int K, int n_tiles, F value /* (n, k) -> W[n][k] or 0 */) {
+    const size_t base = dst.size();
+    const int kbn = mcg_kblocks16(K);
+    dst.resize(base + (size_t)kbn * 3 * n_tiles * 64 * 8, 0);
+    uint16_t* d = dst.data() + base;
+    for (int kb = 0; kb < kbn; ++kb)
+        for (int nt = 0; nt < n_tiles; ++nt)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 32 * kb + 8 * (l >> 4) + j;
+                    float r = k < K ? value(nt * 16 + (l & 15), k) : 0.f;
+                    for (int part = 0; part < 3; ++part) {
+                        const uint16_t hb = mcg_f32_to_bf16_bits(r);
+                        d[((((size_t)kb * 3 + part) * n_tiles + nt) * 64 + l) * 8 + j] = hb;
+                        uint32_t u = (uint32_t)hb << 16;
+                        float f;
+                        __builtin_memcpy(&f, &u, 4);
+                        r -= f;
+                    }
+                }
+}
+__host__ __device__ static inline size_t mcg_pack16x3_elems(int K, int n_tiles) { return 3 * mcg_pack16_elems(K, n_tiles); }
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int RN>
+__global__ __launch_bounds__(256) void mcg_gemm_x6_kernel(McgGemmArgs p) {
+    __shared__ __attribute__((aligned(16))) uint16_t a_lds[2 * 2 * 3 * 64 * 8];      // [2][row tile][part][lane][8] = 12 KiB
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    // a workgroup = 32 rows x (4 waves x RN column tiles); unlike mcg_gemm_kernel all four waves MUST share the row
+    // block (they split it together), so the grid is (row blocks) x (groups of 4 wave columns)
+    const int wave_cols = (p.n_tiles + RN - 1) / RN;
+    const int col_groups = (wave_cols + 3) / 4;
+    const int blk = MCG_GEMM_BLOCK(blockIdx.x, gridDim.x);
+    const int row0 = (blk / col_groups) * 32;
+    const int wcol = (blk % col_groups) * 4 + wid;
+    const bool wave_live = wcol < wave_cols;
+    const int nt0 = (wave_live ? wcol : wave_cols - 1) * RN;
+    bool nvalid[RN];
+    int ncl[RN];
+#pragma unroll
+    for (int n = 0; n < RN; ++n) {
+        nvalid[n] = wave_live && nt0 + n < p.n_tiles;
+        ncl[n] = nt0 + n < p.n_tiles ? n : 0;
+    }
+    f32x4 acc[2][RN];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < RN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ebias[RN];
+    f32x4 eres[2][RN];
+#pragma unroll
+    for (int n = 0; n < RN; ++n) {
+        const int col = (nt0 + ncl[n]) * 16 + 4 * g;
+        ebias[n] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int orow = row0 + 16 * m + c;
+            eres[m][n] = (p.resid && orow < p.M && col + 3 < p.n_store) ? *reinterpret_cast<const f32x4*>(p.resid + (size_t)orow * p.ldr + col)
+                                                                        : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // my quarter of the 32 x 32 activation block: row 8*wid + lane/8, k = 4*(lane%8) .. +3 of the block
+    const int my_row = 8 * wid + (lane >> 3), my_k = 4 * (lane & 7);
+    const int src_row = row0 + my_row < p.M ? row0 + my_row : p.M - 1;
+    // where those 4 values live in fragment layout: tile my_row/16, fragment lane (k/8)*16 + row%16, element k%8
+    const int frag_off = (((my_row >> 4) * 3) * 64 + ((my_k >> 3) * 16 + (my_row & 15))) * 8 + (my_k & 7);
+
+    const uint16_t* bseg = reinterpret_cast<const uint16_t*>(p.Bp);
+    int stage = 0;                       // running k-block counter across both K segments (LDS ring phase)
+#pragma unroll 1
+    for (int seg = 0; seg < 2; ++seg) {
+        const float* A = seg == 0 ? p.A1 : p.A2;
+        const int K = seg == 0 ? p.K1 : p.K2;
+        const int lda = seg == 0 ? p.lda1 : p.lda2;
+        if (K == 0) continue;
+        const int blocks = mcg_kblocks16(K);
+        const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, 0xffffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(bseg), 0, 0xffffffff, 0x00020000);
+        const unsigned oa = (unsigned)(src_row * lda + my_k) * 4u;
+        unsigned obn[RN];
+#pragma unroll
+        for (int n = 0; n < RN; ++n) obn[n] = (unsigned)((nt0 + ncl[n]) * 64 + lane) * 16u;
+        const int part_bytes = p.n_tiles * 64 * 16;
+        auto ld = [](const __amdgpu_buffer_rsrc_t& r, unsigned v, int so) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)v, so, 0); };
+        auto load_a = [&](int kb) { return __builtin_bit_cast(f32x4, ld(rs_a, oa, 128 * (kb < blocks ? kb : blocks - 1))); };
+        bf16x8 Br[2][3][RN];
+        auto load_b = [&](int slot, int kb) {
+            kb = kb < blocks ? kb : blocks - 1;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int n = 0; n < RN; ++n) Br[slot][q][n] = __builtin_bit_cast(bf16x8, ld(rs_b, obn[n], (kb * 3 + q) * part_bytes));
+        };
+        // split 4 fp32 values into three bf16 parts and publish them into ring half `half`
+        auto split_store = [&](f32x4 v, int half) {
+            uint16_t* dst = a_lds + half * (2 * 3 * 64 * 8) + frag_off;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                bf16x4 part;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) part[j] = (__bf16)v[j];
+                *reinterpret_cast<bf16x4*>(dst + q * 64 * 8) = part;
+                if (q < 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] -= (float)part[j];
+                }
+            }
+        };
+        // prologue of the segment: block 0's A parts, B of blocks 0 and 1
+        __syncthreads();                                   // previous segment's last reads of the ring are done
+        split_store(load_a(0), stage & 1);
+        f32x4 a_pref = load_a(1);                          // activation quarter-block, fetched TWO blocks ahead of its split
+        load_b(0, 0);
+        load_b(1, 1);
+        auto block = [&](int slot, int kb) {
+            const int half = (stage + kb) & 1;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");               // A parts of block kb visible; other half free
+            const f32x4 an = a_pref;
+            a_pref = load_a(kb + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8* la = reinterpret_cast<const bf16x8*>(a_lds) + half * (2 * 3 * 64) + lane;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                bf16x8 af[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) af[q] = la[(m * 3 + q) * 64];
+                // weight part q meets activation parts 0 .. 2-q (the six products of weight >= 2^-16);
+                // transposed accumulators: weights are the MFMA A operand (see mcg_gemm_kernel)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int r = 0; r < 3 - q; ++r)
+#pragma unroll
+                        for (int n = 0; n < RN; ++n) acc[m][n] = mcg_mfma_bf16(Br[slot][q][n], af[r], acc[m][n]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(slot, kb + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            split_store(an, half ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int kb = 0;
+#pragma unroll 1
+        for (; kb + 2 <= blocks; kb += 2) { block(0, kb); block(1, kb + 1); }
+        if (kb < blocks) block(0, kb);
+        stage += blocks;
+        bseg += mcg_pack16x3_elems(K, p.n_tiles);
+    }
+#pragma unroll
+    for (int n = 0; n < RN; ++n) {
+        if (!nvalid[n]) continue;
+        const int col = (nt0 + n) * 16 + 4 * g;
+        if (col >= p.n_store) continue;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int orow = row0 + 16 * m + c;
+            if (orow >= p.M) continue;
+            f32x4 v = acc[m][n] + ebias[n];
+            if (p.act == MCG_ACT_SILU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = mcg_silu(v[r]);
+            } else if (p.act == MCG_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            v += eres[m][n];
+            float* dst = p.C + (size_t)orow * p.ldc + col;
+            if (col + 3 < p.n_store) {
+                *reinterpret_cast<f32x4*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (col + r < p.n_store) dst[r] = v[r];
+            }
+        }
+    }
+}
+
+// launch of the f32x6 variant: Bp must point to a B-pack16x3
+static inline hipError_t mcg_gemm_x6_launch(const McgGemmArgs& a, hipStream_t s) {
+    if (a.M <= 0) return hipSuccess;
+    const int rowblocks = (a.M + 31) / 32;
+    // 4 waves x RN tiles per workgroup: RN = 3 covers 12 tiles; pick the width that wastes the fewest wave slots
+    int rn = a.M > 4096 ? 2 : 1;          // measured: RN = 1 at config 2 (3.43 vs 3.66 ms per call for RN = 3), RN = 2 at config 3
+    if (const char* e = getenv("MCG_GEMM_X6_RN")) { const int v = atoi(e); if (v >= 1 && v <= 3) rn = v; }
+    const int wave_cols = (a.n_tiles + rn - 1) / rn;
+    dim3 grid((unsigned)(rowblocks * ((wave_cols + 3) / 4)));
+    if (rn == 3) hipLaunchKernelGGL(mcg_gemm_x6_kernel<3>, grid, dim3(256), 0, s, a);
+    else if (rn == 2) hipLaunchKernelGGL(mcg_gemm_x6_kernel<2>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(mcg_gemm_x6_kernel<1>, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 template <int RN, int RING = 3>
 __global__ __launch_bounds__(256) void mcg_gemm_kernel(McgGemmArgs p) {
     const int lane = threadIdx.x & 63;
