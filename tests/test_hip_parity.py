@@ -559,6 +559,14 @@ def test_config2_full_batch_one_call_vs_oracle(dyn, edm_sd):
     out = dyn.run(plan, t.to(DEV), z.to(DEV), ctx.to(DEV)).cpu()
     ok, err, sc = close(out, ref)
     assert ok, f"err {err} scale {sc}"
+    # the same full-size call in the split-operand mode, same tolerance
+    from ml_conformer_generator_amd.egnn import EGNNDynamics
+    d6 = EGNNDynamics(device=DEV)
+    d6.load_reference_state_dict(edm_sd)
+    d6.set_precision("f32x6")
+    out6 = d6(t.reshape(B, 1).to(DEV), z.to(DEV), nm.to(DEV), em.to(DEV), ctx.to(DEV)).cpu()
+    ok, err, sc = close(out6, ref)
+    assert ok, f"f32x6 err {err} scale {sc}"
 
 
 def test_generator_loads_reference_format_checkpoint_files(edm_sd, gcn_sd, tmp_path):
