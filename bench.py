@@ -313,6 +313,8 @@ def main():
             cfg_label = "configs[1]"
         elif B == 256 and args.variance == 12 and args.n_atoms == 27:
             cfg_label = "configs[2] shape" if world == 1 else "configs[3] shape (256/GPU)"
+        elif B == 4 and args.variance == 2 and args.n_atoms == 17 and args.diffusion_steps == 20:
+            cfg_label = "configs[0] shape (ceyyag: 17 heavy atoms +-2, 4 samples, T=20)"
         else:
             cfg_label = "custom"
         if args.fragment:
