@@ -839,3 +839,36 @@ def test_sampler_trajectory_in_f32x6_mode_vs_golden(edm_sd):
     assert rel < 1e-3, rel
     assert torch.equal(h.cpu().argmax(2) * nm.squeeze(2).long(), g["h"].argmax(2) * nm.squeeze(2).long())
     assert float((x.cpu() - g["x"]).abs().max()) / float(g["x"].abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("mode", ["f32", "f32x6", "bf16"])
+def test_randomized_batch_shapes_vs_oracle(edm_sd, mode):
+    """Random batch compositions (1..24 molecules of 2..42 atoms, pad width up to 42, both plan families, tiles
+    that straddle many small molecules) against the oracle: fp32 tolerance for the exact and split-operand modes,
+    the stated bf16 tolerance (3e-2 of max|out|) for the bf16 mode."""
+    from ml_conformer_generator_amd.egnn import EGNNDynamics
+    from oracle import egnn_oracle as EO
+    from oracle import host_oracle as HO
+    d = EGNNDynamics(device=DEV)
+    d.load_reference_state_dict(edm_sd)
+    d.set_precision(mode)
+    g = torch.Generator().manual_seed(2024)
+    for trial in range(10):
+        B = int(torch.randint(1, 25, (1,), generator=g))
+        lo = [2, 6, 15][trial % 3]
+        hi = [9, 42, 39][trial % 3]
+        sizes = torch.randint(lo, hi + 1, (B,), generator=g)
+        N = int(sizes.max()) + int(torch.randint(0, 3, (1,), generator=g))
+        N = min(N, 42)
+        nm, em = HO.masks_from_sizes(sizes, N)
+        z = torch.randn(B, N, 11, generator=g) * nm
+        ctx = torch.randn(B, 1, 3, generator=g).repeat(1, N, 1) * nm
+        t = torch.rand(B, 1, generator=g)
+        ref = EO.egnn_dynamics(edm_sd, t, z, nm, em, ctx)
+        out = d(t.to(DEV), z.to(DEV), nm.to(DEV), em.to(DEV), ctx.to(DEV)).cpu()
+        assert float((out * (1 - nm)).abs().max()) == 0.0
+        if mode == "bf16":
+            assert float((out - ref).abs().max()) <= 3e-2 * max(1.0, float(ref.abs().max())), (trial, B, sizes.tolist())
+        else:
+            ok, err, sc = close(out, ref)
+            assert ok, (trial, B, sizes.tolist(), err, sc)
