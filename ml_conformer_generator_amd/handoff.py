@@ -145,15 +145,42 @@ def valence_proxy_valid(atomic_numbers: torch.Tensor, bonds: torch.Tensor, n: in
     return bool(reach.all())
 
 
+def valence_proxy_valid_batch(elements: torch.Tensor, bonds: torch.Tensor, n_nodes: torch.Tensor) -> torch.Tensor:
+    """`valence_proxy_valid` for a whole batch as tensor algebra (any device): elements [B,D] atomic numbers,
+    bonds [B,D,D] symmetric bond orders, n_nodes [B] -> bool [B].  Connectivity is the boolean closure of
+    (bond > 0) | I by repeated squaring (6 squarings cover paths up to 64 atoms)."""
+    B, D = elements.shape
+    dev = elements.device
+    real = torch.arange(D, device=dev).unsqueeze(0) < n_nodes.to(dev).reshape(B, 1)
+    pair = real.unsqueeze(1) & real.unsqueeze(2)
+    b = bonds.to(torch.long) * pair
+    val = torch.tensor(_BOND_VALENCE, device=dev)[b].sum(2)
+    maxv_table = torch.zeros(36, device=dev)
+    for z, v in _MAX_VALENCE.items():
+        maxv_table[z] = float(v)
+    maxv = maxv_table[elements.clamp(0, 35)]
+    valence_ok = ~(((val > maxv + 1e-6) & real).any(1))
+    adj = (((b > 0) | torch.eye(D, dtype=torch.bool, device=dev).unsqueeze(0)) & pair).to(torch.float32)
+    reach = adj
+    for _ in range(6):
+        reach = (torch.bmm(reach, reach) > 0).to(torch.float32)
+    connected = ((reach[:, 0, :] > 0) | ~real).all(1)
+    return valence_ok & connected & (n_nodes.to(dev).reshape(B) > 0)
+
+
 def assemble_molecules(x: torch.Tensor, elements: torch.Tensor, bond: torch.Tensor, n_nodes: torch.Tensor
                        ) -> List[GeneratedMolecule]:
-    """One D2H copy of (x, elements, bond) and a cheap per-molecule host pass."""
-    xc, ec, bc, nc = x.cpu(), elements.cpu(), bond.cpu(), n_nodes.cpu()
+    """Batched bond write-back + validity proxy on the tensors' device, ONE D2H copy of (x, elements, bonds,
+    valid), then a slicing-only host pass (the reference standardises one molecule at a time,
+    conformer_generator.py:362-366)."""
+    low = torch.tril(bond.to(torch.int8), diagonal=-1)
+    sym = low + low.transpose(-1, -2)                                    # mol_utils.py:210-211
+    valid = valence_proxy_valid_batch(elements, sym, n_nodes)
+    xc, ec, bc, nc, vc = x.cpu(), elements.cpu(), sym.cpu(), n_nodes.cpu(), valid.cpu()
     out = []
     for b in range(xc.shape[0]):
         n = int(nc[b])
-        bo = bonds_lower_triangle(bc[b])[:n, :n]
-        mol = GeneratedMolecule([int(v) for v in ec[b, :n]], xc[b, :n].clone(), bo)
-        mol.valid = valence_proxy_valid(ec[b], bonds_lower_triangle(bc[b]), n)
+        mol = GeneratedMolecule(ec[b, :n].tolist(), xc[b, :n].clone(), bc[b, :n, :n].clone())
+        mol.valid = bool(vc[b])
         out.append(mol)
     return out

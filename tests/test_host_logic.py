@@ -185,3 +185,34 @@ def test_batched_principal_frames_match_reference_on_cpu_tensors():
         assert float((mom[i] - g[f"moments_{n}"]).abs().max()) < 2e-5, n
         assert float((frames[i, : nn[i]] - g[f"frame_{n}"]).abs().max()) < 2e-5, n
         assert float(frames[i, nn[i]:].abs().max() if nn[i] < N else 0.0) == 0.0
+
+
+def test_batched_validity_proxy_equals_scalar_proxy():
+    """`valence_proxy_valid_batch` (tensor algebra, used by assemble_molecules) against the per-molecule
+    `valence_proxy_valid` on chains with random extra bonds, broken chains (disconnected) and over-valent atoms."""
+    from ml_conformer_generator_amd.handoff import (assemble_molecules, bonds_lower_triangle, valence_proxy_valid,
+                                                    valence_proxy_valid_batch)
+    g = torch.Generator().manual_seed(5)
+    B, D = 64, 42
+    n = torch.randint(3, 40, (B,), generator=g)
+    el = torch.zeros(B, D, dtype=torch.long)
+    bond = torch.zeros(B, D, D, dtype=torch.int8)
+    for b in range(B):
+        nn = int(n[b])
+        el[b, :nn] = torch.tensor([6, 6, 6, 7, 8])[torch.randint(0, 5, (nn,), generator=g)]
+        for i in range(1, nn):
+            if b % 4 != 1 or i != nn // 2:                       # every 4th molecule gets a broken chain
+                bond[b, i, i - 1] = 1
+        if b % 4 == 2:                                           # over-valent: a triple + double bond on one atom
+            bond[b, 1, 0] = 3
+            bond[b, 2, 1] = 2
+        if b % 4 == 3 and nn > 6:                                # ring closure
+            bond[b, 5, 0] = 1
+    sym = torch.stack([bonds_lower_triangle(bond[b]) for b in range(B)])
+    batch = valence_proxy_valid_batch(el, sym, n)
+    scalar = [valence_proxy_valid(el[b], sym[b], int(n[b])) for b in range(B)]
+    assert batch.tolist() == scalar
+    assert 10 < sum(scalar) < B - 10                              # the cases above really split both ways
+    mols = assemble_molecules(torch.randn(B, D, 3), el, bond, n)
+    assert [m.valid for m in mols] == scalar
+    assert all(m.bond_orders.shape == (int(n[b]), int(n[b])) for b, m in enumerate(mols))
