@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The built library is git-ignored: a fresh checkout that runs the tests before `__graft_entry__.build()`
+    gets it built here (hipcc cross-compiles gfx950 without a GPU).  Building is not a fallback: the product still
+    refuses to run without the library."""
+    lib = os.path.join(REPO, "ml_conformer_generator_amd", "libmlconfgen_hip.so")
+    if not os.path.exists(lib) and not os.environ.get("MCG_LIB_PATH"):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(REPO, "ml_conformer_generator_amd", "csrc"), "-j4"], check=False)
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
     return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fi" and z[k].ndim > 0 else z[k]) for k in z.files}
