@@ -220,6 +220,17 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", torch.cuda.current_device())
 
+    lib_path = os.path.join(REPO, "ml_conformer_generator_amd", "libmlconfgen_hip.so")
+    if not os.path.exists(lib_path):          # fresh checkout: the library is git-ignored; local rank 0 builds it
+        if local_rank == 0:
+            import subprocess
+            subprocess.run(["make", "-C", os.path.join(REPO, "ml_conformer_generator_amd", "csrc"), "-j4"], check=True,
+                           stdout=sys.stderr)
+        else:
+            for _ in range(600):
+                if os.path.exists(lib_path):
+                    break
+                time.sleep(0.5)
     from ml_conformer_generator_amd import MLConformerGenerator
     from ml_conformer_generator_amd import weights as W
     from ml_conformer_generator_amd.distributed import gather_results, rank_seed
