@@ -1682,6 +1682,14 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
         nn[b] = n_nodes_host[b];
         node_off[b + 1] = node_off[b] + nn[b];
         row_off[b + 1] = row_off[b] + nn[b] * (nn[b] > 0 ? nn[b] - 1 : 0);
+        // 32-bit row / byte offsets (buffer-descriptor addressing): <= 1e6 atoms and 2^30 edge rows per plan,
+        // i.e. ~37 000 molecules of 27 atoms - shard larger batches over plans / ranks
+        if (node_off[b + 1] > 1000000 || row_off[b + 1] > (1 << 30)) {
+            mcg_set_error("mcg_plan_create: batch too large for one plan (%d atoms after molecule %d; limit 1e6 atoms, 2^30 edge rows)",
+                          node_off[b + 1], b);
+            delete p;
+            return MCG_ERR_ARG;
+        }
     }
     p->M = node_off[B];
     p->n_rows = row_off[B];

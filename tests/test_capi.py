@@ -57,3 +57,16 @@ def test_cpu_device_is_rejected():
     from ml_conformer_generator_amd import MLConformerGenerator
     with pytest.raises(ValueError, match="no CPU fallback"):
         MLConformerGenerator(device=torch.device("cpu"), edm_weights={}, adj_mat_seer_weights={})
+
+
+def test_plan_size_limit_is_reported_not_overflowed():
+    """32-bit offsets inside the kernels: a plan beyond 1e6 atoms is refused with a message (no GPU work: the check
+    precedes every allocation)."""
+    import ctypes as C
+    import numpy as np
+    from ml_conformer_generator_amd import _lib
+    L = _lib.lib()
+    n = np.full(30000, 39, dtype=np.int32)                      # 1.17e6 atoms
+    h = C.c_void_p()
+    rc = L.mcg_plan_create(30000, 39, n.ctypes.data_as(C.c_void_p), 0, C.byref(h))
+    assert rc != 0 and b"too large" in L.mcg_last_error()
