@@ -218,78 +218,9 @@ __device__ __forceinline__ void edge_epilogue(const EdgeArgs& p, int wave, bool 
     }
 }
 
-// ---- v1: one independent wave per workgroup, B fragments straight from global/L2 ------------
-template <int MT, bool EQUIV>
-__global__ __launch_bounds__(64) void k_edge(EdgeArgs p) {
-    const int lane = threadIdx.x;
-    const int g = lane >> 4, c = lane & 15;
-    const int wave = blockIdx.x;
-    RowInfo<MT> R;
-    edge_decode<MT, EQUIV>(p, wave, true, c, R);
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const float* pa[MT];
-    const float* pb[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        pa[mt] = p.pab + (size_t)R.ni[mt] * (2 * HP) + 4 * g;
-        pb[mt] = p.pab + (size_t)R.nj[mt] * (2 * HP) + HP + 4 * g;
-    }
-    const float* bp = p.Bp + lane;
-
-    // ---- main loop: 26 groups of 16 k  (k = 16q + 4g + s)
-#pragma unroll 1
-    for (int q = 0; q < H / 16; ++q) {
-        const f32x4 wdv = *reinterpret_cast<const f32x4*>(p.wd + 16 * q + 4 * g);
-        const f32x4 w0v = *reinterpret_cast<const f32x4*>(p.wd0 + 16 * q + 4 * g);
-        f32x4 a4[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 va = *reinterpret_cast<const f32x4*>(pa[mt] + 16 * q);
-            const f32x4 vb = *reinterpret_cast<const f32x4*>(pb[mt] + 16 * q);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float pre = fmaf(w0v[s], R.d02[mt], fmaf(wdv[s], R.d2[mt], va[s] + vb[s]));
-                a4[mt][s] = mcg_silu(pre);
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float b = bp[nt * 64];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mcg_mfma(a4[mt][s], b, acc[mt][nt]);
-            }
-            bp += NT * 64;
-        }
-    }
-    {   // tail k-step: k = 416 + g
-        const int k = (H / 16) * 16 + g;
-        const float wdk = p.wd[k], w0k = p.wd0[k];
-        float a1[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const float va = p.pab[(size_t)R.ni[mt] * (2 * HP) + k];
-            const float vb = p.pab[(size_t)R.nj[mt] * (2 * HP) + HP + k];
-            a1[mt] = mcg_silu(fmaf(w0k, R.d02[mt], fmaf(wdk, R.d2[mt], va + vb)));
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float b = bp[nt * 64];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mcg_mfma(a1[mt], b, acc[mt][nt]);
-        }
-    }
-    edge_epilogue<MT, EQUIV>(p, wave, true, lane, acc, R, p.b2, p.wv);
-}
-
-// ---- v2: 4 waves per workgroup share the packed W2 through LDS --------------------------------
+// ---- throughput kernel: 4 waves per workgroup share the packed W2 through LDS -------------------
+// (its predecessor - one independent wave per workgroup with B fragments straight from L2 - reached 40 % of the
+//  fp32 MFMA peak: hipcc keeps only 6-10 loads in flight, less than an L2 latency)
 // W2 is streamed global -> LDS with the asynchronous LDS-DMA (global_load_lds, 16 B/lane, no VGPR
 // round trip) one 16-k group (4 MFMA k-steps x 27 column tiles = 27 KB) ahead of the MFMAs that
 // consume it, double-buffered; each wave reads its B fragments back with conflict-free
@@ -1099,28 +1030,10 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
     }
 }
 
-// agg[v] = (sum of the per-wave partials that cover node v) / 100   (egnn.py:429-435)
-__global__ __launch_bounds__(128) void k_combine_agg(const float* __restrict__ P, const int* __restrict__ node_mol,
-                                                      const int* __restrict__ node_off, const int* __restrict__ row_off,
-                                                      const int* __restrict__ n_nodes, const int* __restrict__ wave_nf,
-                                                      const int* __restrict__ wave_poff, int rows_per_wave,
-                                                      float* __restrict__ agg) {
-    const int v = blockIdx.x;
-    const int b = node_mol[v];
-    const int n = n_nodes[b];
-    const int i = v - node_off[b];
-    const int first = row_off[b] + i * (n - 1);
-    const int w_lo = first / rows_per_wave, w_hi = (first + n - 2) / rows_per_wave;
-    for (int col = threadIdx.x; col < HP; col += 128) {
-        float s = 0.f;
-        if (n > 1)
-            for (int w = w_lo; w <= w_hi; ++w) s += P[(size_t)(wave_poff[w] + v - wave_nf[w]) * HP + col];
-        agg[(size_t)v * HP + col] = s / NORM;
-    }
-}
-
-// Same two reductions driven by a per-node table of partial-slot indices built once per plan
-// (node_slots[v][0..7], -1 = unused): one table load instead of a chain of four dependent lookups.
+// agg[v] = (sum of the per-wave partials that cover node v) / 100   (egnn.py:429-435), and the coordinate
+// update below: driven by a per-node table of partial-slot indices built once per plan (node_slots[v][0..7],
+// -1 = unused; a node's rows span at most ceil((n-2)/16) + 1 <= 4 tiles for n <= 42), summed in ascending
+// slot order - deterministic, no atomics.
 __global__ __launch_bounds__(128) void k_combine_agg_t(const float* __restrict__ P, const int* __restrict__ node_slots,
                                                         float* __restrict__ agg) {
     const int v = blockIdx.x;
@@ -1149,25 +1062,6 @@ __global__ void k_coord_update_t(const float* __restrict__ Px, const int* __rest
         if (sl >= 0) { s += Px[(size_t)sl * 4 + comp]; any = true; }
     }
     if (any) x[(size_t)v * 4 + comp] += s / NORM;
-}
-
-// x[v] = x[v] + (sum of partials) / 100   (egnn.py:128-134; node mask is implicit)
-__global__ void k_coord_update(const float* __restrict__ Px, const int* __restrict__ node_mol,
-                               const int* __restrict__ node_off, const int* __restrict__ row_off,
-                               const int* __restrict__ n_nodes, const int* __restrict__ wave_nf,
-                               const int* __restrict__ wave_poff, int rows_per_wave, int M, float* __restrict__ x) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int v = idx >> 2, comp = idx & 3;
-    if (v >= M || comp == 3) return;
-    const int b = node_mol[v];
-    const int n = n_nodes[b];
-    if (n <= 1) return;
-    const int i = v - node_off[b];
-    const int first = row_off[b] + i * (n - 1);
-    const int w_lo = first / rows_per_wave, w_hi = (first + n - 2) / rows_per_wave;
-    float s = 0.f;
-    for (int w = w_lo; w <= w_hi; ++w) s += Px[(size_t)(wave_poff[w] + v - wave_nf[w]) * 4 + comp];
-    x[(size_t)v * 4 + comp] += s / NORM;
 }
 
 // ------------------------------------------------------------------------------ output head
@@ -1438,8 +1332,6 @@ int build_node_layer(mcg_egnn* m, NodeLayer& L, const float* w3 /*[420][840]*/, 
     return MCG_OK;
 }
 
-int g_edge_variant = -1;   // 0: v1 (direct global B), 1: v2 (LDS-staged B); env MCG_EDGE_KERNEL
-
 // f32x6 / f32x9 modes: node-side GEMMs on the split-operand kernel too (MCG_X6_GEMM=0: exact fp32 GEMMs)
 static bool g_x6_gemm() {
     static int v = -1;
@@ -1449,18 +1341,9 @@ static bool g_x6_gemm() {
 
 template <int MT>
 void launch_edge(bool equiv, const EdgeArgs& a, int n_waves, hipStream_t s) {
-    if (g_edge_variant < 0) {
-        const char* e = getenv("MCG_EDGE_KERNEL");
-        g_edge_variant = e ? atoi(e) : 1;
-    }
-    if (g_edge_variant >= 1) {
-        const int wgs = (n_waves + 3) / 4;
-        if (equiv) hipLaunchKernelGGL((k_edge_lds<MT, true>), dim3(wgs), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_edge_lds<MT, false>), dim3(wgs), dim3(256), 0, s, a);
-        return;
-    }
-    if (equiv) hipLaunchKernelGGL((k_edge<MT, true>), dim3(n_waves), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((k_edge<MT, false>), dim3(n_waves), dim3(64), 0, s, a);
+    const int wgs = (n_waves + 3) / 4;
+    if (equiv) hipLaunchKernelGGL((k_edge_lds<MT, true>), dim3(wgs), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_edge_lds<MT, false>), dim3(wgs), dim3(256), 0, s, a);
 }
 
 int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipStream_t s, bool bf16 = false, int x6 = 0) {
@@ -1492,8 +1375,9 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
             if (equiv) hipLaunchKernelGGL((k_edge_lds_bf16<1, true>), dim3(wgs), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((k_edge_lds_bf16<1, false>), dim3(wgs), dim3(256), 0, s, a);
         } else {
-            if (equiv) hipLaunchKernelGGL((k_edge_lds_bf16<2, true>), dim3(wgs), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((k_edge_lds_bf16<2, false>), dim3(wgs), dim3(256), 0, s, a);
+            // (a 32-rows-per-wave bf16 variant was measured slower - 235 vs 180 us at config 3 - and removed)
+            mcg_set_error("bf16 mode: plans need edge_mt = 1 (16-row tiles) or 4 (64-row units)");
+            return MCG_ERR_STATE;
         }
         MCG_HIP(hipGetLastError());
         return MCG_OK;
@@ -1546,11 +1430,7 @@ int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s) {
     if (int e = run_edge(pl, E, false, pl->P, s, lp, m->x6)) return e;
     // (reading the partials directly in the node GEMM's A-loader was tried: the 4-way gather costs the
     //  GEMM as much as the ~6 us combine launch it saves at config 2 and more at config 3)
-    if (pl->node_slots)
-        hipLaunchKernelGGL(k_combine_agg_t, dim3(M), dim3(128), 0, s, pl->P, pl->node_slots, pl->agg);
-    else
-        hipLaunchKernelGGL(k_combine_agg, dim3(M), dim3(128), 0, s, pl->P, pl->node_mol, pl->node_off, pl->row_off,
-                           pl->n_nodes, pl->wave_nf, pl->wave_poff, 16 * pl->MT, pl->agg);
+    hipLaunchKernelGGL(k_combine_agg_t, dim3(M), dim3(128), 0, s, pl->P, pl->node_slots, pl->agg);
     MCG_HIP(hipGetLastError());
     // node_mlp: h + W4 silu(W3 [h | agg] + b3) + b4   (egnn.py:30-34,66-67)
     if (int e = gemm(pl->h, HP, H, pl->agg, HP, H, Nl.w3_Bp, Nl.b3, nullptr, 0, pl->t1, HP, M, NT, HP, MCG_ACT_SILU, s,
@@ -1568,11 +1448,7 @@ int run_equiv(const mcg_egnn* m, mcg_plan* pl, int block, hipStream_t s) {
                      MCG_ACT_NONE, s, m->bf16 ? E.pab_Bp16 : nullptr, (m->x6 != 0 && g_x6_gemm()) ? E.pab_Bp16x3 : nullptr)) return e;
     if (int e = run_edge(pl, E, true, pl->Px, s, m->bf16, m->x6)) return e;
     const int threads = M * 4;
-    if (pl->node_slots)
-        hipLaunchKernelGGL(k_coord_update_t, dim3((threads + 255) / 256), dim3(256), 0, s, pl->Px, pl->node_slots, M, pl->x);
-    else
-        hipLaunchKernelGGL(k_coord_update, dim3((threads + 255) / 256), dim3(256), 0, s, pl->Px, pl->node_mol, pl->node_off,
-                           pl->row_off, pl->n_nodes, pl->wave_nf, pl->wave_poff, 16 * pl->MT, M, pl->x);
+    hipLaunchKernelGGL(k_coord_update_t, dim3((threads + 255) / 256), dim3(256), 0, s, pl->Px, pl->node_slots, M, pl->x);
     MCG_HIP(hipGetLastError());
     return MCG_OK;
 }
@@ -1758,10 +1634,13 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
         p->row_ij = reinterpret_cast<int2*>(d);
         p->allocs.push_back(d);
     }
-    if (slots_ok && p->M > 0) {
-        e |= upload_i(node_slots, &p->node_slots);
-        p->allocs.push_back(p->node_slots);
+    if (!slots_ok) {
+        mcg_set_error("mcg_plan_create: a molecule's edge rows span more than 8 tiles per atom (N > 114 is not supported)");
+        mcg_plan_destroy(p);
+        return MCG_ERR_ARG;
     }
+    e |= upload_i(node_slots, &p->node_slots);
+    p->allocs.push_back(p->node_slots);
     e |= upload_i(nn, &p->n_nodes); e |= upload_i(node_off, &p->node_off); e |= upload_i(row_off, &p->row_off);
     e |= upload_i(tile_mol, &p->tile_mol); e |= upload_i(wave_nf, &p->wave_nf); e |= upload_i(wave_poff, &p->wave_poff);
     e |= upload_i(node_mol, &p->node_mol);

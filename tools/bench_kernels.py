@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmarks on the GPU box: edge kernel per launch, one full denoiser call (phi).
-Usage: python tools/bench_kernels.py [--shape c2|c3] [--mt 0|1|2]   (MCG_EDGE_KERNEL=0/1 selects v1/v2)"""
+Usage: python tools/bench_kernels.py [--shape c2|c3] [--mt 0|1|2]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -36,5 +36,5 @@ ms_eq = timed(lambda: L.mcg_bench_edge(dyn.handle, plan.handle, 4, 1, 10, st), 5
 ms_phi = timed(lambda: dyn.run(plan, t, z, ctx, out), a.iters)
 E = plan.n_real_edges
 fl = 2.0 * E * (420 * 420 + 3 * 420)
-print(f"dtype={a.dtype} shape={a.shape} variant={os.environ.get('MCG_EDGE_KERNEL','1')} mt={plan.edge_mt} waves={plan.n_edge_waves} E={E} M={plan.n_real_nodes} "
+print(f"dtype={a.dtype} shape={a.shape} mt={plan.edge_mt} waves={plan.n_edge_waves} E={E} M={plan.n_real_nodes} "
       f"edge_gcl={ms_edge*1e3:.1f}us ({fl/ms_edge/1e9:.1f} TF/s) edge_equiv={ms_eq*1e3:.1f}us phi={ms_phi:.3f}ms")
