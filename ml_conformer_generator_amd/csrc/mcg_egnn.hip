@@ -1009,16 +1009,50 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) sel[mt][r] = rseg[mt][r] == (c >> 2) + 4 * (c & 3) ? mcg_sigmoid(dot[mt][r] + p.bv) : 0.f;
-        // the 16 MFMAs of one column tile are a dependent chain: run the wave's 7 chains interleaved
         f32x4 d[NS_T];
 #pragma unroll
         for (int i = 0; i < NS_T; ++i) d[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (SPLIT == 1) {
+            // bf16 mode: the segmented, gate-scaled sum on the bf16 pipe with two-part operands (hi + lo, three
+            // products: relative error 2^-16 on a quantity the mode's 3e-3 tolerance does not see) instead of 16
+            // fp32 MFMAs per column tile - 6 x 16 cycles instead of 16 x 32.  Contraction slot j of lane group g
+            // stands for row (tile 2h + j/4, 4g + j%4) on BOTH operands, so the B operand is just the lane's own
+            // accumulator registers of the two row tiles and the A operand its own gate values.
+            auto split2 = [](const float (&v)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+                for (int j = 0; j < 8; ++j) hi[j] = (__bf16)v[j];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int j = 0; j < 8; ++j) lo[j] = (__bf16)(v[j] - (float)hi[j]);
+            };
 #pragma unroll
-                for (int i = 0; i < NS_T; ++i) d[i] = mcg_mfma(sel[mt][t], acc[mt][i][t], d[i]);
+            for (int h2 = 0; h2 < 2; ++h2) {
+                float gv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gv[j] = sel[2 * h2 + (j >> 2)][j & 3];
+                bf16x8 g_hi, g_lo;
+                split2(gv, g_hi, g_lo);
+#pragma unroll
+                for (int i = 0; i < NS_T; ++i) {
+                    float mv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) mv[j] = acc[2 * h2 + (j >> 2)][i][j & 3];
+                    bf16x8 m_hi, m_lo;
+                    split2(mv, m_hi, m_lo);
+                    d[i] = mcg_mfma_bf16(g_hi, m_hi, d[i]);
+                    d[i] = mcg_mfma_bf16(g_lo, m_hi, d[i]);
+                    d[i] = mcg_mfma_bf16(g_hi, m_lo, d[i]);
+                }
+            }
+        } else {
+            // split-operand modes keep this sum exact (fp32 MFMA).  The 16 MFMAs of one column tile are a dependent
+            // chain: run the wave's 7 chains interleaved
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < NS_T; ++i) d[i] = mcg_mfma(sel[mt][t], acc[mt][i][t], d[i]);
+        }
 #pragma unroll
         for (int i = 0; i < NS_T; ++i) {
             const int nt = wid + 4 * i;
