@@ -6,7 +6,10 @@
  * replaces.  Plain pointers and sizes only; every float buffer is fp32, row-major, contiguous and
  * lives in DEVICE memory unless the name ends in `_host`.  `stream` is a hipStream_t (0 = default).
  * All functions return 0 on success (MCG_OK) or a non-zero code; mcg_last_error() gives the text.
- * No global mutable state except the opaque handles.
+ * No global mutable state except the opaque handles.  Threading: like the reference (single Python thread, one
+ * stream) - a handle carries workspace, so one mcg_plan / mcg_gcn must not run on two host threads or two streams at
+ * once; different handles are independent, mcg_egnn weights are read-only after creation (mcg_egnn_set_precision
+ * excepted) and may be shared by several plans.  mcg_last_error() is thread-local.
  */
 #ifndef MLCONFGEN_HIP_H
 #define MLCONFGEN_HIP_H
