@@ -51,6 +51,9 @@ int mcg_egnn_set_precision(mcg_egnn* m, int mode);
  * and the node/edge masks (mol_utils.py:226-252): node_mask[b] is the prefix of n_nodes_host[b]
  * ones, edge_mask = outer product minus diagonal.  edge_mt: 0 = auto, 1..2 = rows/16 per wave. */
 int mcg_plan_create(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_plan** out);
+/* Same, with the number of independent molecule ranges (each runs the whole denoiser on its own HIP stream inside
+ * mcg_egnn_dynamics; 0 = the library's choice: 2 from 8 192 edge tiles on, 1 below) given by the caller. */
+int mcg_plan_create_ranges(int B, int N, const int32_t* n_nodes_host, int edge_mt, int n_ranges, mcg_plan** out);
 void mcg_plan_destroy(mcg_plan* p);
 /* Edge-kernel choice: -1 auto (the column-split latency kernel when the batch has <= 512 edge tiles,
  * else the throughput kernel), 0 = always throughput, 1 = always latency (needs edge_mt 1). */

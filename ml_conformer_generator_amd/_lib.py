@@ -24,6 +24,7 @@ SIGNATURES: Dict[str, tuple] = {
     "mcg_egnn_destroy": (None, [_vp]),
     "mcg_egnn_set_precision": (_i, [_vp, _i]),
     "mcg_plan_create": (_i, [_i, _i, _vp, _i, _pp]),
+    "mcg_plan_create_ranges": (_i, [_i, _i, _vp, _i, _i, _pp]),
     "mcg_plan_destroy": (None, [_vp]),
     "mcg_plan_info": (_i, [_vp, _vp]),
     "mcg_plan_set_latency_mode": (_i, [_vp, _i]),

@@ -1712,12 +1712,17 @@ void mcg_plan_destroy(mcg_plan* p) {
     delete p;
 }
 
-static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, int edge_mt);
+static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, int edge_mt, int n_ranges);
 
 int mcg_plan_create(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_plan** out) {
+    return mcg_plan_create_ranges(B, N, n_nodes_host, edge_mt, 0, out);
+}
+
+int mcg_plan_create_ranges(int B, int N, const int32_t* n_nodes_host, int edge_mt, int n_ranges, mcg_plan** out) {
+    if (n_ranges < 0 || n_ranges > 4) { mcg_set_error("mcg_plan_create_ranges: n_ranges must be 0 (auto) .. 4"); return MCG_ERR_ARG; }
     mcg_plan* p = nullptr;
     if (int e = plan_create_single(B, N, n_nodes_host, edge_mt, &p)) return e;
-    if (int e = plan_finish(p, B, N, n_nodes_host, edge_mt)) {
+    if (int e = plan_finish(p, B, N, n_nodes_host, edge_mt, n_ranges)) {
         mcg_plan_destroy(p);          // streams, events, sub-plans and buffers created so far
         return e;
     }
@@ -1726,7 +1731,7 @@ int mcg_plan_create(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_
 }
 
 // graph staging buffer, capture stream and the optional split into molecule ranges
-static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, int edge_mt) {
+static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, int edge_mt, int n_ranges) {
     MCG_HIP(hipMalloc((void**)&p->t_buf, (size_t)B * sizeof(float)));
     p->allocs.push_back(p->t_buf);
     MCG_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
@@ -1734,7 +1739,9 @@ static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, i
     // Measured (tools/bench_kernels.py): 2 ranges are 7 % faster at config 3 (12 k edge tiles = 12 rounds
     // of the chip) but 12 % slower at config 2 (2.8 k tiles: halving them wrecks the tile quantisation),
     // so the split is only taken when every range still fills the chip several times over.
-    int parts = p->n_mtiles >= 8192 ? 2 : 1;
+    // (The split-operand modes profit earlier - f32x6 at config 2: 3.53 -> 3.18 ms per call - because their edge
+    // kernel is short against the node phase; their host mirror asks for two ranges explicitly.)
+    int parts = n_ranges > 0 ? n_ranges : (p->n_mtiles >= 8192 ? 2 : 1);
     if (const char* e = getenv("MCG_SPLIT")) parts = atoi(e);
     if (parts < 2 || B < 2 * parts || p->n_rows < 4096) return MCG_OK;
     std::vector<long> cum(B + 1, 0);

@@ -21,7 +21,8 @@ class BatchPlan:
     """Batch geometry (molecule sizes -> compact node/edge tiling) + device workspace.
     Replaces the reference's per-call `get_adj_matrix` and mask tensors."""
 
-    def __init__(self, n_nodes: torch.Tensor, max_n_nodes: int, device: torch.device, edge_mt: int = 0):
+    def __init__(self, n_nodes: torch.Tensor, max_n_nodes: int, device: torch.device, edge_mt: int = 0,
+                 n_ranges: int = 0):
         L = _lib.lib()
         n_host = n_nodes.detach().to("cpu", torch.int32).contiguous().reshape(-1)
         self.B = int(n_host.numel())
@@ -30,8 +31,8 @@ class BatchPlan:
         self.n_nodes_host = n_host
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(L.mcg_plan_create(self.B, self.N, n_host.data_ptr(), int(edge_mt), C.byref(self._h)),
-                       "mcg_plan_create")
+            _lib.check(L.mcg_plan_create_ranges(self.B, self.N, n_host.data_ptr(), int(edge_mt), int(n_ranges),
+                                                C.byref(self._h)), "mcg_plan_create_ranges")
         info = torch.zeros(8, dtype=torch.int32)
         _lib.check(L.mcg_plan_info(self._h, info.data_ptr()), "mcg_plan_info")
         (self.n_real_nodes, self.n_real_edges, self.edge_mt, self.n_edge_waves, self.n_pslots, _, _,
@@ -129,12 +130,18 @@ class EGNNDynamics(torch.nn.Module):
     def plan(self, n_nodes: torch.Tensor, max_n_nodes: int, edge_mt: int = 0) -> BatchPlan:
         if edge_mt == 0 and self.compute_dtype in ("bf16", "f32x6", "f32x9") and int(n_nodes.min()) >= 6:
             edge_mt = 4          # 64-row workgroup tiles (needs <= 16 nodes per 64 edge rows)
+        # split-operand modes: two molecule ranges on two streams from ~1 500 edge tiles on (their edge kernel is short
+        # against the node phase, which the other range's edge kernel then overlaps: 3.53 -> 3.18 ms at config 2)
+        n_ranges = 0
+        if edge_mt == 4 and self.compute_dtype in ("f32x6", "f32x9"):
+            nn = n_nodes.reshape(-1).to(torch.long)
+            n_ranges = 2 if int((nn * (nn - 1)).sum()) >= 1500 * 16 else 1
         key = (int(max_n_nodes), int(edge_mt), tuple(int(v) for v in n_nodes.reshape(-1).tolist()))
         p = self._plans.get(key)
         if p is None:
             if len(self._plans) >= 4:
                 self._plans.pop(next(iter(self._plans)))
-            p = BatchPlan(n_nodes, max_n_nodes, self.device, edge_mt)
+            p = BatchPlan(n_nodes, max_n_nodes, self.device, edge_mt, n_ranges)
             self._plans[key] = p
         return p
 

@@ -8,6 +8,7 @@ from ml_conformer_generator_amd.egnn import EGNNDynamics
 from ml_conformer_generator_amd.equivariant_diffusion import EquivariantDiffusion, PredefinedNoiseSchedule
 dev = torch.device("cuda:0")
 dyn = EGNNDynamics(device=dev); dyn.load_reference_state_dict(W.synth_edm_state_dict(1234))
+dyn.set_precision(os.environ.get("MCG_DTYPE", "f32"))
 T = 50
 gm = EquivariantDiffusion(dynamics=dyn, in_node_nf=8, timesteps=1000, noise_precision=1e-5)
 gm.gamma = PredefinedNoiseSchedule(timesteps=T, precision=1e-5); gm.T = T
