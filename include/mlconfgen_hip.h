@@ -6,7 +6,19 @@
  * replaces.  Plain pointers and sizes only; every float buffer is fp32, row-major, contiguous and
  * lives in DEVICE memory unless the name ends in `_host`.  `stream` is a hipStream_t (0 = default).
  * All functions return 0 on success (MCG_OK) or a non-zero code; mcg_last_error() gives the text.
- * No global mutable state except the opaque handles.  Threading: like the reference (single Python thread, one
+ * No global mutable state except the opaque handles and the process-wide measurement switches below, which are
+ * read from the environment (MCG_GRAPH, MCG_X6_GEMM and MCG_NS_MAX_TILES once, on first use, and then cached for the
+ * life of the process; the others at every plan creation / launch) - none is needed for normal operation:
+ *   MCG_GRAPH=0          plain launches instead of the captured HIP graph per denoiser call
+ *   MCG_NS_MAX_TILES=n   largest batch (16-row edge tiles) that takes the column-split latency edge kernel (512)
+ *   MCG_EDGE_MT=1|2      rows/16 per wave of the exact-fp32 edge kernel for new plans
+ *   MCG_SPLIT=n          molecule ranges (HIP streams) per plan, overriding the library's choice
+ *   MCG_FUSED_NODE=0     node phase as separate launches instead of the fused node-phase kernel
+ *   MCG_GEMM_RN=1..3, MCG_GEMM_X6_RN=1..3   wave tile width of the node GEMMs
+ *   MCG_X6_GEMM=0        f32x6 / f32x9 modes: node GEMMs on the exact fp32 kernel
+ *   MCG_VERBOSE=1        graph capture diagnostics on stderr
+ * (Python side: MCG_LIB_PATH = alternative library file, MCG_FORCE_COLLECTIVE=1 = run the final gather on a 1-rank
+ * group.)  Threading: like the reference (single Python thread, one
  * stream) - a handle carries workspace, so one mcg_plan / mcg_gcn must not run on two host threads or two streams at
  * once; different handles are independent, mcg_egnn weights are read-only after creation (mcg_egnn_set_precision
  * excepted) and may be shared by several plans.  mcg_last_error() is thread-local.
@@ -127,6 +139,21 @@ int mcg_gcn_check(mcg_gcn* g);
  * x[B,N,3], h[B,N,8] one-hot and n_nodes[B] (device int32).  Atoms keep their generation order. */
 int mcg_handoff(const float* x, const float* h, const int32_t* n_nodes_dev, int B, int N, float cov_factor,
                 int64_t* elements, float* dist_mat, float* adj_mat, void* stream);   /* non-zero if an element id outside [0,36) was seen */
+
+/* Bond write-back + validity pre-filter behind the GCN (replaces the tensor half of `redefine_bonds`,
+ * utils/mol_utils.py:197-223, and stands in for `standardize_mol(...) is not None`, conformer_generator.py:362-366 /
+ * utils/standardizer.py:83-111, which is RDKit sanitisation + MMFF and cannot run without RDKit):
+ * bond[B,42,42] int8 = argmax bond classes from mcg_gcn_forward; bond_sym[B,42,42] int8 = its strict lower triangle
+ * mirrored, zero outside the molecule's n x n block; valid[B] uint8 = 1 when no atom exceeds its maximum valence and
+ * the bond graph is one connected fragment (a labelled PROXY, not RDKit's gate). */
+int mcg_bond_writeback(const int8_t* bond, const int64_t* elements, const int32_t* n_nodes_dev, int B, int8_t* bond_sym,
+                       uint8_t* valid, void* stream);
+/* Inertial fragment matching, the tensor work between its two sampler runs (`inverse_coord_transform`,
+ * utils/mol_utils.py:508-524, then `ifm_prepare_fragments_for_merge`, :460-505) in one launch:
+ * z_known[B,N,11] = [fixed fragment (ff_x[n_ff,3] | ff_h[n_ff,8]) ; gen_x[B,n_gen,3] @ rotation[B,3,3]^T - shift[B,3] |
+ * gen_h[B,n_gen,8]], zero rows up to N; fixed_mask[B,N,1] = 1 on the first n_ff rows.  n_ff + n_gen <= N. */
+int mcg_ifm_merge(const float* ff_x, const float* ff_h, int n_ff, const float* gen_x, const float* gen_h, int n_gen,
+                  const float* shift, const float* rotation, int B, int N, float* z_known, float* fixed_mask, void* stream);
 
 /* ---- Evaluation (grid half): Gaussian-volume shape Tanimoto of one reference against B
  * candidates in R orientations - `tanimoto_score` (cheminformatics/shape_similarity.py:468-492) for every

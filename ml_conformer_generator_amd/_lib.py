@@ -44,6 +44,8 @@ SIGNATURES: Dict[str, tuple] = {
     "mcg_gcn_check": (_i, [_vp]),
     "mcg_shape_tanimoto": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp]),
     "mcg_handoff": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "mcg_bond_writeback": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "mcg_ifm_merge": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -5,8 +5,12 @@ Same constructor kwargs, method names, argument order and errors as
 forced by the scope of this build:
   * `device` must be a ROCm GPU (default cuda:0): there is no CPU path;
   * `edm_weights` / `adj_mat_seer_weights` may also be an in-memory state dict;
-  * without RDKit the RDKit-owned stages are replaced by the native hand-off of
-    `handoff.py` and results are `GeneratedMolecule` records instead of `Chem.Mol`.
+  * the RDKit-owned stages are replaced by the native hand-off of `handoff.py` (two HIP
+    launches) and results are `GeneratedMolecule` records instead of `Chem.Mol`
+    (`.to_molblock()` feeds them to RDKit where it exists; an RDKit Mol is still accepted
+    as the reference conformer / fixed fragment);
+  * `generate_conformers_sharded(...)`: the same call, batch-sharded over the ranks of an
+    initialised `torch.distributed` group (one process per GPU, one gather at the end).
 """
 from __future__ import annotations
 
@@ -20,11 +24,12 @@ from .config import (ATOM_DECODER, CONTEXT_NORMS, DIMENSION, MAX_N_NODES, MIN_N_
                      NUM_BOND_TYPES)
 from .egnn import EGNNDynamics
 from .equivariant_diffusion import EquivariantDiffusion, PredefinedNoiseSchedule
-from .handoff import (GeneratedMolecule, assemble_molecules, prepare_adj_mat_seer_input_hip,
-                      prepare_adj_mat_seer_input_native)
-from .mol_utils import (get_context_shape, ifm_get_xh_from_fragment, ifm_prepare_fragments_for_merge,
-                        ifm_prepare_gen_fragment_context, inverse_coord_transform, parse_molblock_heavy_atoms,
-                        prepare_edm_input, prepare_fragment)
+from . import distributed as mcg_dist
+from .handoff import (GeneratedMolecule, assemble_molecules, bond_writeback_hip, molecules_from_tensors,
+                      prepare_adj_mat_seer_input_hip)
+from .mol_utils import (get_context_shape, ifm_get_xh_from_fragment, ifm_merge_hip,
+                        ifm_prepare_gen_fragment_context, parse_molblock_heavy_atoms, prepare_edm_input,
+                        prepare_fragment)
 
 try:  # RDKit is optional on this path
     from rdkit import Chem  # type: ignore
@@ -77,19 +82,26 @@ class MLConformerGenerator(torch.nn.Module):
         self.generative_model = generative_model
         self.adj_mat_seer = adj_mat_seer
         self.last_batch = None       # tensors of the most recent generation (x, h, n_nodes, bond)
+        self.last_valid_fraction = None   # share of the last batch that passed the validity proxy
+        self._timing = None          # bench.py: {"sampler_start", "sampler_end"} events recorded around the sampler
 
     # ------------------------------------------------------------------ EDM stage
     @torch.no_grad()
     def edm_tensors(self, reference_context: torch.Tensor, n_samples: int = 100, max_n_nodes: int = 32,
                     min_n_nodes: int = 25, resample_steps: int = 0, fixed_fragment=None,
-                    inertial_fragment_matching: bool = True, blend_power: int = 3, ifm_diffusion_level: int = 50):
-        """Tensor form of `edm_samples` (conformer_generator.py:125-266): x[B,N,3], h[B,N,8], node_mask."""
+                    inertial_fragment_matching: bool = True, blend_power: int = 3, ifm_diffusion_level: int = 50,
+                    sizes: Optional[torch.Tensor] = None):
+        """Tensor form of `edm_samples` (conformer_generator.py:125-266): x[B,N,3], h[B,N,8], node_mask.
+        `sizes`: molecule sizes drawn by the caller (the sharded path) instead of here."""
         min_n_nodes = max(min_n_nodes, self.min_n_nodes)            # :156-160
         max_n_nodes = min(max_n_nodes, self.max_n_nodes)
         node_mask, edge_mask, batch_context = prepare_edm_input(
             n_samples=n_samples, reference_context=reference_context, context_norms=self.context_norms,
-            min_n_nodes=min_n_nodes, max_n_nodes=max_n_nodes, device=self.device)
+            min_n_nodes=min_n_nodes, max_n_nodes=max_n_nodes, device=self.device, sizes=sizes)
         gm = self.generative_model
+        ev = self._timing
+        if ev is not None:
+            ev["sampler_start"].record()
         if fixed_fragment is None:
             x, h = gm(node_mask, edge_mask, batch_context, resample_steps)
         elif inertial_fragment_matching:
@@ -101,10 +113,8 @@ class MLConformerGenerator(torch.nn.Module):
                 context_norms=self.context_norms, max_n_nodes=max_n_nodes, min_n_nodes=min_n_nodes,
                 device=self.device)
             xg, hg = gm(f_nm, f_em, f_ctx, resample_steps)
-            xg = inverse_coord_transform(coord=xg, shift=shift, rotation=rotation)
-            z_known, fixed_mask = ifm_prepare_fragments_for_merge(
-                fixed_fragment_x=ff_x, fixed_fragment_h=ff_h.to(torch.float32), gen_fragments_x=xg,
-                gen_fragments_h=hg, device=self.device, max_n_nodes=max_n_nodes)
+            # inverse_coord_transform + ifm_prepare_fragments_for_merge: one HIP launch on the device outputs
+            z_known, fixed_mask = ifm_merge_hip(ff_x, ff_h, xg, hg, shift, rotation, self.device, max_n_nodes)
             x, h = gm.merge_fragments(node_mask=node_mask, edge_mask=edge_mask, fixed_mask=fixed_mask,
                                       context=batch_context, z_known=z_known, diffusion_level=ifm_diffusion_level,
                                       resample_steps=resample_steps, blend_power=blend_power)
@@ -113,23 +123,25 @@ class MLConformerGenerator(torch.nn.Module):
                                                    max_n_nodes=max_n_nodes, min_n_nodes=min_n_nodes,
                                                    device=self.device)
             x, h = gm.inpaint(node_mask, edge_mask, batch_context, z_known, fixed_mask, resample_steps, blend_power)
+        if ev is not None:
+            ev["sampler_end"].record()
         return x, h, node_mask
 
     @torch.no_grad()
     def edm_samples(self, reference_context: torch.Tensor, n_samples: int = 100, max_n_nodes: int = 32,
                     min_n_nodes: int = 25, resample_steps: int = 0, fixed_fragment=None,
                     inertial_fragment_matching: bool = True, blend_power: int = 3, ifm_diffusion_level: int = 50):
-        """Samples without bonds: RDKit mols when RDKit is present, else GeneratedMolecule records."""
+        """Samples without bonds (conformer_generator.py:125-266) as GeneratedMolecule records."""
         x, h, node_mask = self.edm_tensors(reference_context, n_samples, max_n_nodes, min_n_nodes, resample_steps,
                                            fixed_fragment, inertial_fragment_matching, blend_power,
                                            ifm_diffusion_level)
-        if HAVE_RDKIT:
-            from .rdkit_glue import samples_to_rdkit_mol
-            return samples_to_rdkit_mol(positions=x, one_hot=h, node_mask=node_mask, atom_decoder=self.atom_decoder)
         n_nodes = node_mask.sum(1).reshape(-1).to(torch.long)
-        el, _, _ = prepare_adj_mat_seer_input_native(x, h, n_nodes, self.dimension)
-        no_bonds = torch.zeros(x.shape[0], self.dimension, self.dimension, dtype=torch.int8)
-        return assemble_molecules(x, el, no_bonds, n_nodes)
+        el, _, _ = prepare_adj_mat_seer_input_hip(x, h, n_nodes, self.dimension)
+        no_bonds = torch.zeros(x.shape[0], self.dimension, self.dimension, dtype=torch.int8, device=x.device)
+        mols = assemble_molecules(x, el, no_bonds, n_nodes)
+        for m in mols:
+            m.valid = True          # no bonds yet: the connectivity proxy does not apply
+        return mols
 
     # ------------------------------------------------------------------ full pipeline
     def _reference_context(self, reference_conformer, reference_context, n_atoms):
@@ -153,6 +165,32 @@ class MLConformerGenerator(torch.nn.Module):
         raise ValueError(
             "Either a reference RDkit Mol object or context as torch.Tensor should be provided for generation.")
 
+    def _generate_shard(self, ref_context, ref_n_atoms: int, variance: int, sizes: Optional[torch.Tensor],
+                        n_samples: int, resample_steps, fixed_fragment, inertial_fragment_matching, blend_power,
+                        ifm_diffusion_level):
+        """Sampler -> hand-off -> GCN -> bond write-back + validity proxy for `n_samples` molecules on THIS device.
+        Returns per-sample DEVICE tensors (dim 0 = n_samples; n_samples may be 0 for an empty shard)."""
+        N = min(ref_n_atoms + variance, self.max_n_nodes)
+        D = self.dimension
+        dev = self.device
+        if n_samples == 0:
+            return dict(x=torch.zeros(0, N, 3, device=dev), elements=torch.zeros(0, D, dtype=torch.int8, device=dev),
+                        bond=torch.zeros(0, D, D, dtype=torch.int8, device=dev),
+                        n_nodes=torch.zeros(0, dtype=torch.int32, device=dev),
+                        valid=torch.zeros(0, dtype=torch.uint8, device=dev))
+        x, h, node_mask = self.edm_tensors(
+            reference_context=ref_context, n_samples=n_samples, min_n_nodes=ref_n_atoms - variance,
+            max_n_nodes=ref_n_atoms + variance, resample_steps=resample_steps, fixed_fragment=fixed_fragment,
+            inertial_fragment_matching=inertial_fragment_matching, blend_power=blend_power,
+            ifm_diffusion_level=ifm_diffusion_level, sizes=sizes)
+        n_nodes = node_mask.sum(1).reshape(-1).to(torch.long)
+        el, dm, am = prepare_adj_mat_seer_input_hip(x, h, n_nodes, D)
+        bond = self.adj_mat_seer.bond_orders(el, dm, am)
+        sym, valid = bond_writeback_hip(bond, el, n_nodes)
+        self.last_batch = dict(x=x, h=h, n_nodes=n_nodes, elements=el, bond=bond)
+        return dict(x=x, elements=el.to(torch.int8), bond=sym, n_nodes=n_nodes.to(torch.int32),
+                    valid=valid.to(torch.uint8))
+
     @torch.no_grad()
     def generate_conformers(self, reference_conformer=None, n_samples: int = 10, variance: int = 2,
                             reference_context: torch.Tensor = None, n_atoms: int = None,
@@ -160,21 +198,47 @@ class MLConformerGenerator(torch.nn.Module):
                             inertial_fragment_matching: bool = True, blend_power: int = 3,
                             ifm_diffusion_level: int = 50) -> List:
         """Generate molecules from a reference shape (conformer_generator.py:268-368).
-        Returns the VALID molecules only (invalid ones are dropped, as in the reference)."""
+        Returns the VALID molecules only (invalid ones are dropped, as in the reference); without RDKit
+        "valid" is the labelled valence / single-fragment proxy of `mcg_bond_writeback`.
+        `optimise_geometry` is accepted for signature parity: MMFF is RDKit's and does not run here."""
         ref_context, ref_n_atoms = self._reference_context(reference_conformer, reference_context, n_atoms)
-        x, h, node_mask = self.edm_tensors(
-            reference_context=ref_context, n_samples=n_samples, min_n_nodes=ref_n_atoms - variance,
-            max_n_nodes=ref_n_atoms + variance, resample_steps=resample_steps, fixed_fragment=fixed_fragment,
-            inertial_fragment_matching=inertial_fragment_matching, blend_power=blend_power,
-            ifm_diffusion_level=ifm_diffusion_level)
-        n_nodes = node_mask.sum(1).reshape(-1).to(torch.long)
-        if HAVE_RDKIT:
-            from .rdkit_glue import finish_with_rdkit
-            return finish_with_rdkit(self, x, h, node_mask, optimise_geometry)
-        el, dm, am = prepare_adj_mat_seer_input_hip(x, h, n_nodes, self.dimension)
-        bond = self.adj_mat_seer.bond_orders(el, dm, am)
-        self.last_batch = dict(x=x, h=h, n_nodes=n_nodes, elements=el, bond=bond)
-        mols = assemble_molecules(x, el, bond, n_nodes)           # single D2H
+        res = self._generate_shard(ref_context, ref_n_atoms, variance, None, n_samples, resample_steps, fixed_fragment,
+                                   inertial_fragment_matching, blend_power, ifm_diffusion_level)
+        mols = molecules_from_tensors(res["x"], res["elements"], res["bond"], res["n_nodes"], res["valid"])   # single D2H
+        self.last_valid_fraction = (sum(m.valid for m in mols) / len(mols)) if mols else 0.0
+        return [m for m in mols if m.valid]
+
+    @torch.no_grad()
+    def generate_conformers_sharded(self, reference_conformer=None, n_samples: int = 10, variance: int = 2,
+                                    reference_context: torch.Tensor = None, n_atoms: int = None,
+                                    optimise_geometry: bool = True, resample_steps: int = 0, fixed_fragment=None,
+                                    inertial_fragment_matching: bool = True, blend_power: int = 3,
+                                    ifm_diffusion_level: int = 50, group=None, seed: Optional[int] = None) -> List:
+        """`generate_conformers` for `n_samples` molecules in TOTAL, sharded over the ranks of the initialised
+        `torch.distributed` group (one process per GPU, each with its own generator instance / weight replica;
+        SURVEY.md section 8e).  The global size vector is drawn once on rank 0 and broadcast, rank r generates
+        the contiguous slice `shard_range(n_samples, r, world)`, and ONE all-gather of the result tensors at the
+        end gives every rank the full batch, in sample order.  `seed`: per-rank noise seed `seed + rank` for the
+        device generator (None leaves the generators alone).  Without an initialised group this is
+        `generate_conformers`."""
+        ref_context, ref_n_atoms = self._reference_context(reference_conformer, reference_context, n_atoms)
+        lo_n = max(ref_n_atoms - variance, self.min_n_nodes)
+        hi_n = min(ref_n_atoms + variance, self.max_n_nodes)
+
+        def run_shard(sizes_shard, lo, hi):
+            return self._generate_shard(ref_context, ref_n_atoms, variance, sizes_shard, hi - lo, resample_steps,
+                                        fixed_fragment, inertial_fragment_matching, blend_power, ifm_diffusion_level)
+
+        def seed_device(s):
+            if self.device.type == "cuda":
+                with torch.cuda.device(self.device):
+                    torch.cuda.manual_seed(s)
+
+        _, res = mcg_dist.sharded_generate(
+            n_samples, lambda: mcg_dist.draw_global_sizes(n_samples, lo_n, hi_n, group), run_shard, group=group,
+            seed=seed, seed_fn=seed_device)
+        mols = molecules_from_tensors(res["x"], res["elements"], res["bond"], res["n_nodes"], res["valid"])
+        self.last_valid_fraction = (sum(m.valid for m in mols) / len(mols)) if mols else 0.0
         return [m for m in mols if m.valid]
 
     @torch.no_grad()

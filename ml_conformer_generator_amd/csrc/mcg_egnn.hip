@@ -18,6 +18,7 @@
 #include "mcg_gemm.h"
 #include "mcg_api_internal.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -75,8 +76,8 @@ struct EdgeArgs {
     float bv;               // attention bias (GCL)
     const int* n_nodes; const int* node_off; const int* row_off; int B;
     const int* tile_mol;    // molecule of the first row of every 16-row tile
-    const int2* row_ij;     // [n_mtiles*16] compact node ids (i, j) of every edge row, (-1,-1) on the padded tail
-    const int* wave_nf;     // first compact node touched by each wave
+    const int2* row_ij;     // [n_mtiles*16] (i, j | seg << 24) of every edge row: compact node ids + the row's
+                            // segment inside its unit; (-1,-1) on the padded tail
     const int* wave_poff;   // prefix offsets of (wave, node) partial slots
     int n_rows; int n_mtiles; int n_waves;
     float* P;               // GCL: [n_pslots][HP] partial sums;  equiv: [n_pslots][4]
@@ -90,17 +91,18 @@ struct RowInfo {            // per-lane facts about its A-operand rows (row = ti
 
 template <int MT, bool EQUIV>
 __device__ __forceinline__ void edge_decode(const EdgeArgs& p, int wave, bool live, int c, RowInfo<MT>& R) {
-    const int nf = p.wave_nf[wave];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int tile = wave * MT + mt;
         const int r = tile * 16 + c;
         // one 8-byte load instead of the tile -> molecule -> (row_off, n, node_off) -> division chain: the row
-        // decode sits at the head of every workgroup's dependent-load chain and nothing overlaps it
+        // decode sits at the head of every workgroup's dependent-load chain and nothing overlaps it.
+        // .y carries j in its low 24 bits and the row's segment (rank of node i among the nodes that own rows
+        // of this unit, < 16 by plan construction) above them.
         int vi = 0, vj = 0, sg = -1;
         if (live && tile < p.n_mtiles) {
             const int2 ij = p.row_ij[r];
-            if (ij.x >= 0) { vi = ij.x; vj = ij.y; sg = vi - nf; }
+            if (ij.x >= 0) { vi = ij.x; vj = ij.y & 0xffffff; sg = ij.y >> 24; }
         }
         R.ni[mt] = vi; R.nj[mt] = vj; R.seg[mt] = sg;
         const f32x4 xi = *reinterpret_cast<const f32x4*>(p.x + (size_t)vi * 4);
@@ -229,12 +231,6 @@ __device__ __forceinline__ void edge_epilogue(const EdgeArgs& p, int wave, bool 
 constexpr int GROUP_FLOATS = 4 * NT * 64;          // 6912 floats = 27 KiB: one 16-k group of B-pack
 constexpr int GROUP_LDS_FLOATS = 28 * 256;         // 7 x 1 KiB pieces per wave x 4 waves = 28 KiB
 constexpr int PD = 6;                              // depth of the B-fragment register ring
-#ifndef MCG_PRIO
-#define MCG_PRIO 0
-#endif
-#ifndef MCG_ABLATE
-#define MCG_ABLATE 0   // measurement builds only: 1 skip epilogue, 2 skip A-gen math, 4 skip LDS staging + barriers, 8 skip A loads (bf16)
-#endif
 
 template <int MT, bool EQUIV>
 __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p) {
@@ -254,11 +250,6 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
     const int wave = live ? wave_raw : p.n_waves - 1;
     RowInfo<MT> R;
     edge_decode<MT, EQUIV>(p, wave, live, c, R);
-#if MCG_PRIO == 1
-    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(1);
-#elif MCG_PRIO == 2
-    if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(1);
-#endif
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -328,20 +319,15 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
     }
 
     constexpr int NG = H / 16;      // 26 full groups, then one tail k-step (k = 416 + g)
-#if MCG_PRIO == 4
-    __builtin_amdgcn_s_setprio(3);
-#endif
 #pragma unroll 1
-    for (int q = 0; q < ((MCG_ABLATE & 16) ? 1 : NG); ++q) {
+    for (int q = 0; q < NG; ++q) {
         const int buf = q & 1;
-#if !(MCG_ABLATE & 4)
         // ONE barrier per group.  The DMA of group q was issued a whole group (~3.5k cycles of MFMA
         // work) ago and this wave's mid-loop operand wait has drained the vector-memory queue since,
         // so "my pieces of group q have landed" is already true here; after the barrier it is true
         // for every wave, and every wave has also finished reading buffer buf^1 (group q-1).
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
-#endif
         // A-operand inputs of the NEXT group (or of the tail step) - ordinary loads, issued first
         f32x4 va[MT], vb[MT], wdv, w0v;
         if (q + 1 < NG) {
@@ -361,9 +347,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
             wdv = (f32x4){p.wd[16 * NG + g], 0.f, 0.f, 0.f};
             w0v = (f32x4){p.wd0[16 * NG + g], 0.f, 0.f, 0.f};
         }
-#if !(MCG_ABLATE & 4)
         stage(q + 1, buf ^ 1);                                     // group q+1 (the tail group when q+1 == NG)
-#endif
         const float* lb = lds + buf * GROUP_LDS_FLOATS + lane;
         f32x4 a4n[MT];
         // B fragments go through a PD-deep register ring: the ds_read of fragment i+PD is issued
@@ -392,12 +376,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(va[mt]), "+v"(vb[mt]));
                 asm volatile("" : "+v"(wdv), "+v"(w0v));
-#if (MCG_ABLATE & 2)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a4n[mt] = va[mt] + vb[mt] + wdv + w0v;
-#else
                 agen(va, vb, wdv, w0v, a4n);
-#endif
             }
         }
 #pragma unroll
@@ -414,21 +393,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
             for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mcg_mfma(a4[mt][0], b, acc[mt][nt]);
         }
     }
-#if MCG_PRIO == 4
-    __builtin_amdgcn_s_setprio(0);
-#endif
-#if (MCG_ABLATE & 1)
-    {
-        float sink = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) sink += acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2] + acc[mt][nt][3];
-        if (sink == 123.456f) p.P[0] = sink;
-    }
-#else
     edge_epilogue<MT, EQUIV>(p, wave, live, lane, acc, R, lds + 2 * GROUP_LDS_FLOATS, lds + 2 * GROUP_LDS_FLOATS + HP);
-#endif
 }
 
 // (A 12-k-group variant of this kernel - 35 groups, no tail step, 51 KiB of LDS, THREE workgroups per CU - was
@@ -691,25 +656,12 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds_bf16(EdgeAr
 #pragma unroll 1
     for (int kb = 0; kb < KB16; ++kb) {
         const int buf = kb & 1;
-#if !(MCG_ABLATE & 4)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my pieces of block kb (issued one block ago)
         asm volatile("s_barrier" ::: "memory");                    // all pieces landed + buffer buf^1 free
-#endif
         f32x4 v[MT][4], w[4];
         const int kn = kb + 1 < KB16 ? kb + 1 : kb;                // (last block: harmless reload)
-#if !(MCG_ABLATE & 8)
         load_a(kn, v, w);
-#else
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[mt][i] = (f32x4){0.1f, 0.2f, 0.3f, 0.4f};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = (f32x4){0.1f, 0.2f, 0.3f, 0.4f};
-#endif
-#if !(MCG_ABLATE & 4)
         stage(kn, buf ^ 1);
-#endif
         const bf16x8* lb = reinterpret_cast<const bf16x8*>(lds + buf * GROUP_LDS_FLOATS) + lane;
         bf16x8 bq[PD16];
 #pragma unroll
@@ -732,29 +684,13 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds_bf16(EdgeAr
                     for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(v[mt][i]));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(w[i]));
-#if (MCG_ABLATE & 2)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a8n[mt] = mcg_pack_bf16(v[mt][0] + w[0], v[mt][1] + w[1]);
-#else
                 agen(v, w, a8n);
-#endif
             }
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a8[mt] = a8n[mt];
     }
-#if (MCG_ABLATE & 1)
-    {
-        float sink = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) sink += acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2] + acc[mt][nt][3];
-        if (sink == 123.456f) p.P[0] = sink;
-    }
-#else
     edge_epilogue<MT, EQUIV>(p, wave, live, lane, acc, R, lds + 2 * GROUP_LDS_FLOATS, lds + 2 * GROUP_LDS_FLOATS + HP);
-#endif
 }
 
 // ---- bf16, 64-row workgroup tiles -------------------------------------------------------------------
@@ -790,7 +726,6 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
     const int unit = mcg_xcd_remap(blockIdx.x, gridDim.x);               // 64-row unit == "wave" of the MT = 4 plan
-    const int nf = p.wave_nf[unit];
 
     // rows of MY row tile (tile wid of the unit): A-operand generation + row facts for everybody's epilogue
     int vi = 0, vj = 0, sg = -1;
@@ -800,7 +735,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
         const int r = tile * 16 + c;
         if (tile < p.n_mtiles) {
             const int2 ij = p.row_ij[r];
-            if (ij.x >= 0) { vi = ij.x; vj = ij.y; sg = vi - nf; }
+            if (ij.x >= 0) { vi = ij.x; vj = ij.y & 0xffffff; sg = ij.y >> 24; }
         }
         const f32x4 xi = *reinterpret_cast<const f32x4*>(p.x + (size_t)vi * 4);
         const f32x4 xj = *reinterpret_cast<const f32x4*>(p.x + (size_t)vj * 4);
@@ -1201,6 +1136,8 @@ struct NodeLayer {
 }  // namespace
 
 struct mcg_egnn {
+    uint64_t uid = 0;           // unique per created model (captured graphs are keyed by it, never by the host address:
+                                // a destroyed model's address is routinely handed out again by the allocator)
     int n_blocks = 0;
     bool bf16 = false;          // MFMA operands rounded to bf16 (opt-in, mcg_egnn_set_precision)
     int x6 = 0;                 // 1 = f32x6: edge second layer as six bf16 partial products of three-part operands
@@ -1215,7 +1152,7 @@ struct mcg_egnn {
 struct mcg_plan {
     int B = 0, N = 0, M = 0, n_rows = 0, n_mtiles = 0, MT = 1, n_waves = 0, n_pslots = 0;
     int2* row_ij = nullptr;
-    int *n_nodes = nullptr, *node_off = nullptr, *row_off = nullptr, *tile_mol = nullptr, *wave_nf = nullptr,
+    int *n_nodes = nullptr, *node_off = nullptr, *row_off = nullptr, *tile_mol = nullptr,
         *wave_poff = nullptr, *node_mol = nullptr, *node_slots = nullptr;   // node_slots: [M][8] or null
     float *x = nullptr, *x0 = nullptr, *h = nullptr, *h2 = nullptr, *pab = nullptr, *agg = nullptr, *t1 = nullptr,
           *P = nullptr, *Px = nullptr;
@@ -1232,7 +1169,7 @@ struct mcg_plan {
     float* t_buf = nullptr;                 // fixed device copy of t[B] read by the captured graph
     hipStream_t cap_stream = nullptr;       // capture happens here (the caller's stream may be the null stream)
     hipGraphExec_t graph_exec = nullptr;
-    const void* g_key[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // xh, context, out, model, bf16
+    const void* g_key[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // xh, context, out, model uid, precision mode
     int graph_failed = 0;
     // Callers whose tensors move between calls (the reference's own sampler loop allocates a fresh xh / out
     // every step) would force a re-capture per call: after the second key change the graph is captured on
@@ -1385,7 +1322,7 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
     EdgeArgs a;
     a.pab = pl->pab; a.x = pl->x; a.x0 = pl->x0; a.wd = L.wd; a.wd0 = L.wd0; a.Bp = L.w2_Bp; a.b2 = L.b2;
     a.wv = L.wv; a.bv = L.bv; a.n_nodes = pl->n_nodes; a.node_off = pl->node_off; a.row_off = pl->row_off;
-    a.B = pl->B; a.tile_mol = pl->tile_mol; a.row_ij = pl->row_ij; a.wave_nf = pl->wave_nf; a.wave_poff = pl->wave_poff;
+    a.B = pl->B; a.tile_mol = pl->tile_mol; a.row_ij = pl->row_ij; a.wave_poff = pl->wave_poff;
     a.n_rows = pl->n_rows; a.n_mtiles = pl->n_mtiles; a.n_waves = pl->n_waves; a.P = P;
     if (x6 && pl->MT == 4) {       // (plans with 16/32-row tiles - molecules below 6 atoms - run the exact fp32 kernels)
         a.Bp = reinterpret_cast<const float*>(L.w2_Bp16x3);
@@ -1551,6 +1488,8 @@ int mcg_egnn_create(const float* const* tensors, int n_tensors, int hidden, int 
         return MCG_ERR_ARG;
     }
     mcg_egnn* m = new mcg_egnn();
+    static std::atomic<uint64_t> next_uid{1};
+    m->uid = next_uid.fetch_add(1);
     if (int e = egnn_build(m, tensors, n_blocks)) {
         mcg_egnn_destroy(m);          // frees whatever was uploaded before the failure
         return e;
@@ -1614,55 +1553,73 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
     p->n_waves = (p->n_mtiles + best - 1) / best;
     const int R = 16 * best;
 
-    std::vector<int> node_mol(p->M), tile_mol(p->n_mtiles + 1, 0), wave_nf(p->n_waves + 1, 0), wave_poff(p->n_waves + 1, 0);
+    std::vector<int> node_mol(p->M), tile_mol(p->n_mtiles + 1, 0), wave_poff(p->n_waves + 1, 0);
     for (int b = 0; b < B; ++b)
         for (int i = 0; i < nn[b]; ++i) node_mol[node_off[b] + i] = b;
-    auto node_of_row = [&](int r, int& bcur) {
-        while (r >= row_off[bcur + 1]) ++bcur;
-        return node_off[bcur] + (r - row_off[bcur]) / (nn[bcur] - 1);
-    };
     {
         int bcur = 0;
         for (int t = 0; t < p->n_mtiles; ++t) {
-            (void)node_of_row(t * 16, bcur);
+            while (t * 16 >= row_off[bcur + 1]) ++bcur;
             tile_mol[t] = bcur;
         }
-        int b1 = 0, b2 = 0;
-        for (int w = 0; w < p->n_waves; ++w) {
-            const int r_first = w * R;
-            const int r_last = std::min(p->n_rows, (w + 1) * R) - 1;
-            const int nfirst = node_of_row(r_first, b1);
-            const int nlast = node_of_row(r_last, b2);
-            wave_nf[w] = nfirst;
-            wave_poff[w + 1] = wave_poff[w] + (nlast - nfirst + 1);
-        }
-        p->n_pslots = wave_poff[p->n_waves];
     }
-    // per-node partial-slot table (ascending wave order = the order the sums are taken in)
+    // (i, j) of every edge row, padded to whole tiles, + the row's SEGMENT inside its unit (R rows): the rank of
+    // node i among the nodes that own rows of the unit.  Counting only row-owning nodes keeps a 16-row tile at
+    // <= 16 segments whatever the molecule sizes (1-atom molecules own node indices but no rows); every epilogue
+    // handles segment ids 0..15, so wider units (edge_mt 2 / 4) are refused when a unit would need more.
+    // Per-node partial-slot table node_slots[v][k] (ascending unit order = the order the sums are taken in).
+    std::vector<int> ij((size_t)(p->n_mtiles > 0 ? p->n_mtiles : 1) * 32, -1);
     std::vector<int> node_slots((size_t)p->M * 8, -1);
-    bool slots_ok = true;
-    for (int b = 0; b < B && slots_ok; ++b) {
-        const int n = nn[b];
-        for (int i = 0; i < n && n > 1; ++i) {
-            const int v = node_off[b] + i;
-            const int first = row_off[b] + i * (n - 1);
-            const int w_lo = first / R, w_hi = (first + n - 2) / R;
-            if (w_hi - w_lo + 1 > 8) { slots_ok = false; break; }
-            for (int w = w_lo; w <= w_hi; ++w) node_slots[(size_t)v * 8 + (w - w_lo)] = wave_poff[w] + v - wave_nf[w];
-        }
-    }
-    int e = 0;
-    {   // (i, j) of every edge row, padded to whole tiles
-        std::vector<int> ij((size_t)(p->n_mtiles > 0 ? p->n_mtiles : 1) * 32, -1);
+    bool slots_ok = true, segs_ok = true;
+    {
+        std::vector<int> unit_nseg(p->n_waves + 1, 0);
+        std::vector<int> row_seg((size_t)p->n_rows, 0);
+        int cur_unit = -1, cur_node = -1, seg = -1;
         for (int b = 0; b < B; ++b) {
             const int n = nn[b];
             for (int i = 0; i < n && n > 1; ++i)
                 for (int jj = 0; jj < n - 1; ++jj) {
-                    const size_t r = (size_t)row_off[b] + (size_t)i * (n - 1) + jj;
-                    ij[2 * r] = node_off[b] + i;
-                    ij[2 * r + 1] = node_off[b] + jj + (jj >= i ? 1 : 0);
+                    const int r = row_off[b] + i * (n - 1) + jj;
+                    const int v = node_off[b] + i;
+                    const int u = r / R;
+                    if (u != cur_unit) { cur_unit = u; cur_node = v; seg = 0; }
+                    else if (v != cur_node) { cur_node = v; ++seg; }
+                    unit_nseg[u] = seg + 1;
+                    row_seg[r] = seg;
                 }
         }
+        for (int w = 0; w < p->n_waves; ++w) {
+            if (unit_nseg[w] > 16) segs_ok = false;
+            wave_poff[w + 1] = wave_poff[w] + unit_nseg[w];
+        }
+        p->n_pslots = wave_poff[p->n_waves];
+        for (int b = 0; b < B && slots_ok; ++b) {
+            const int n = nn[b];
+            for (int i = 0; i < n && n > 1; ++i) {
+                const int v = node_off[b] + i;
+                const int first = row_off[b] + i * (n - 1);
+                const int w_lo = first / R, w_hi = (first + n - 2) / R;
+                if (w_hi - w_lo + 1 > 8) { slots_ok = false; break; }
+                for (int w = w_lo; w <= w_hi; ++w) {
+                    const int r = std::max(first, w * R);         // the node's first row inside unit w
+                    node_slots[(size_t)v * 8 + (w - w_lo)] = wave_poff[w] + row_seg[r];
+                }
+                for (int jj = 0; jj < n - 1; ++jj) {
+                    const size_t r = (size_t)first + jj;
+                    ij[2 * r] = v;
+                    ij[2 * r + 1] = (node_off[b] + jj + (jj >= i ? 1 : 0)) | (row_seg[r] << 24);
+                }
+            }
+        }
+    }
+    if (!segs_ok) {
+        mcg_set_error("mcg_plan_create: edge_mt = %d puts more than 16 atoms' rows into one %d-row unit (molecules this "
+                      "small need edge_mt = 1)", best, R);
+        delete p;
+        return MCG_ERR_ARG;
+    }
+    int e = 0;
+    {
         int* d = nullptr;
         e |= upload_i(ij, &d);
         p->row_ij = reinterpret_cast<int2*>(d);
@@ -1676,11 +1633,11 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
     e |= upload_i(node_slots, &p->node_slots);
     p->allocs.push_back(p->node_slots);
     e |= upload_i(nn, &p->n_nodes); e |= upload_i(node_off, &p->node_off); e |= upload_i(row_off, &p->row_off);
-    e |= upload_i(tile_mol, &p->tile_mol); e |= upload_i(wave_nf, &p->wave_nf); e |= upload_i(wave_poff, &p->wave_poff);
+    e |= upload_i(tile_mol, &p->tile_mol); e |= upload_i(wave_poff, &p->wave_poff);
     e |= upload_i(node_mol, &p->node_mol);
     if (e) { mcg_plan_destroy(p); return MCG_ERR_HIP; }
     p->allocs.insert(p->allocs.end(), {(void*)p->n_nodes, (void*)p->node_off, (void*)p->row_off, (void*)p->tile_mol,
-                                       (void*)p->wave_nf, (void*)p->wave_poff, (void*)p->node_mol});
+                                       (void*)p->wave_poff, (void*)p->node_mol});
     const size_t M1 = (size_t)(p->M > 0 ? p->M : 1);
     struct { float** ptr; size_t n; } bufs[] = {
         // (+64 floats: the bf16 kernels read activation rows up to k = 447, i.e. 16 floats past the last row)
@@ -1834,7 +1791,7 @@ int mcg_egnn_dynamics(const mcg_egnn* m, mcg_plan* pl, const float* t, const flo
         if (out != out_user) MCG_HIP(hipMemcpyAsync(out_user, out, n_xh * sizeof(float), hipMemcpyDeviceToDevice, s));
         return MCG_OK;
     };
-    const void* key[5] = {xh, context, out, m, (const void*)(size_t)(m->bf16 ? 1 : m->x6 ? 1 + m->x6 : 0)};
+    const void* key[5] = {xh, context, out, (const void*)(size_t)m->uid, (const void*)(size_t)(m->bf16 ? 1 : m->x6 ? 1 + m->x6 : 0)};
     if (pl->graph_exec && memcmp(key, pl->g_key, sizeof(key)) == 0) {
         MCG_HIP(hipGraphLaunch(pl->graph_exec, s));
         return finish();

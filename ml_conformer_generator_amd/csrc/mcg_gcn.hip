@@ -149,8 +149,8 @@ struct Lin { float* Bp = nullptr; float* bias = nullptr; int K = 0, n_tiles = 0,
 
 int up(const std::vector<float>& v, float** d, std::vector<void*>& allocs) {
     MCG_HIP(hipMalloc((void**)d, v.size() * sizeof(float)));
+    allocs.push_back(*d);              // owned from here on, also when the copy fails
     MCG_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
-    allocs.push_back(*d);
     return MCG_OK;
 }
 
@@ -185,6 +185,7 @@ struct mcg_gcn {
 namespace {
 int ensure_ws(mcg_gcn* g, int B) {
     if (B <= g->cap) return MCG_OK;
+    g->cap = 0;                       // a failed regrow must not leave the freed buffers looking usable
     for (void* p : g->ws) (void)hipFree(p);
     g->ws.clear();
     struct { float** p; size_t n; } bufs[] = {
@@ -219,9 +220,7 @@ int graph_conv(const Lin& L, const float* Lnorm, const float* in, int in_w, floa
 
 extern "C" {
 
-int mcg_gcn_create(const float* const* t, int n_tensors, mcg_gcn** out) {
-    if (!t || !out || n_tensors != 22) { mcg_set_error("mcg_gcn_create: expected 22 tensors"); return MCG_ERR_ARG; }
-    mcg_gcn* g = new mcg_gcn();
+static int gcn_build(mcg_gcn* g, const float* const* t) {
     int e = 0;
     e |= build_lin(g->gcn[0], t[0], t[1], HID, EMB, EMB, g->allocs);
     e |= build_lin(g->gcn[1], t[2], t[3], HID, HID, HID, g->allocs);
@@ -241,8 +240,18 @@ int mcg_gcn_create(const float* const* t, int n_tensors, mcg_gcn** out) {
     if (up(v, &g->dm_w, g->allocs)) return MCG_ERR_HIP;
     g->dm_b = t[20][0];
     MCG_HIP(hipMalloc((void**)&g->err, sizeof(int)));
-    MCG_HIP(hipMemset(g->err, 0, sizeof(int)));
     g->allocs.push_back(g->err);
+    MCG_HIP(hipMemset(g->err, 0, sizeof(int)));
+    return MCG_OK;
+}
+
+int mcg_gcn_create(const float* const* t, int n_tensors, mcg_gcn** out) {
+    if (!t || !out || n_tensors != 22) { mcg_set_error("mcg_gcn_create: expected 22 tensors"); return MCG_ERR_ARG; }
+    mcg_gcn* g = new mcg_gcn();
+    if (int e = gcn_build(g, t)) {
+        mcg_gcn_destroy(g);           // frees whatever was uploaded before the failure
+        return e;
+    }
     *out = g;
     return MCG_OK;
 }

@@ -3,13 +3,20 @@
 Every sample is independent through the whole path, so a batch of
 `n_samples` is split contiguously over the ranks, each rank runs the full sampler + GCN on
 its shard with its own weight replica, and ONE collective at the very end gathers the small
-result tensors (x f32, atom types int8, bond orders int8, sizes int32) - RCCL over xGMI on
-the GPU box (`backend="nccl"`), gloo in the CPU tests.
+result tensors (x f32, atom types int8, bond orders int8, sizes int32, validity uint8) - RCCL
+over xGMI on the GPU box (`backend="nccl"`), gloo in the CPU tests.
+
+Molecule sizes: the GLOBAL size vector is drawn ONCE, on rank 0, from the CPU global RNG with the
+reference's own draw (`torch.randint(min, max + 1, (n_samples,))`, mol_utils.py:275) and broadcast
+(control plane: n_samples int64); rank r takes the slice `shard_range(n_samples, r, world)`.  A seeded
+single-process run and a sharded run therefore generate the same molecule sizes in the same order.
+Noise: per-rank device generator, seed `seed + rank`; bit-identity of the NOISE with an unsharded run
+is not promised (the reference draws it as one [B,N,*] tensor).
 """
 from __future__ import annotations
 
 import os
-from typing import Dict, List, Tuple
+from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -30,6 +37,35 @@ def rank_seed(seed: int, rank: int) -> int:
     """Per-rank RNG seed (noise is drawn per shard; bit-identity with an unsharded run is not
     promised - the reference draws noise as one [B,N,*] tensor)."""
     return seed + rank
+
+
+def world_and_rank(group=None) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def _collective_device(group=None) -> torch.device:
+    """Where a tensor has to live for this group's collectives: RCCL moves device memory, gloo host memory."""
+    if dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def draw_global_sizes(n_samples: int, min_n_nodes: int, max_n_nodes: int, group=None) -> torch.Tensor:
+    """The sizes of the WHOLE batch [n_samples] int64 (CPU), identical on every rank: drawn on rank 0 with
+    the reference's draw from the CPU global RNG, then broadcast."""
+    world, rank = world_and_rank(group)
+    if world == 1:
+        return torch.randint(min_n_nodes, max_n_nodes + 1, (n_samples,))
+    dev = _collective_device(group)
+    if rank == 0:
+        sizes = torch.randint(min_n_nodes, max_n_nodes + 1, (n_samples,)).to(dev)
+    else:
+        sizes = torch.empty(n_samples, dtype=torch.long, device=dev)
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast(sizes, src=src, group=group)
+    return sizes.cpu()
 
 
 def gather_results(local: Dict[str, torch.Tensor], n_samples: int, group=None) -> Dict[str, torch.Tensor]:
@@ -56,3 +92,31 @@ def gather_results(local: Dict[str, torch.Tensor], n_samples: int, group=None) -
         full = torch.cat(parts, dim=0)
         out[key] = full.to(t.device) if via_host else full
     return out
+
+
+def sharded_generate(n_samples: int, draw_sizes: Callable[[], torch.Tensor],
+                     run_shard: Callable[[torch.Tensor, int, int], Dict[str, torch.Tensor]], group=None,
+                     seed: Optional[int] = None, seed_fn: Optional[Callable[[int], None]] = None
+                     ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+    """The sharded generation step every multi-GPU entry point goes through
+    (`MLConformerGenerator.generate_conformers_sharded`, `bench.py --gpus N`):
+
+      sizes  = draw_sizes() once for the whole batch (identical on every rank, see `draw_global_sizes`)
+      lo, hi = shard_range(n_samples, rank, world)
+      seed_fn(rank_seed(seed, rank))            # per-rank noise stream, when a seed is given
+      local  = run_shard(sizes[lo:hi], lo, hi)  # dict of per-sample tensors, dim 0 = hi - lo (may be 0)
+      full   = gather_results(local)            # the ONLY data-path collective, at the very end
+
+    Returns (sizes, full) on every rank; `full` is in sample order."""
+    world, rank = world_and_rank(group)
+    sizes = draw_sizes()
+    if sizes.numel() != n_samples:
+        raise ValueError(f"draw_sizes() returned {sizes.numel()} sizes for n_samples={n_samples}")
+    lo, hi = shard_range(n_samples, rank, world)
+    if seed is not None and seed_fn is not None:
+        seed_fn(rank_seed(seed, rank))
+    local = run_shard(sizes[lo:hi], lo, hi)
+    for key, t in local.items():
+        if t.shape[0] != hi - lo:
+            raise ValueError(f"run_shard returned {t.shape[0]} rows of `{key}` for a shard of {hi - lo}")
+    return sizes, gather_results(local, n_samples, group)

@@ -101,12 +101,17 @@ class EGNNDynamics(torch.nn.Module):
                 raise RuntimeError(f"size mismatch for {k}: {tuple(t.shape)} vs {tuple(shape)}")
             tensors.append(t)
         arr = _lib.host_ptr_array(tensors)
+        # cached plans hold HIP graphs with the old model's device weight pointers baked in: drop them with it
+        self._plans.clear()
         if self._h:
             L.mcg_egnn_destroy(self._h)
             self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(L.mcg_egnn_create(arr, len(tensors), self.hidden_nf, self.n_blocks, C.byref(self._h)),
                        "mcg_egnn_create")
+        if self.compute_dtype != "f32":          # a fresh C model starts in exact fp32: keep the mode the caller chose
+            dtype, self.compute_dtype = self.compute_dtype, "f32"
+            self.set_precision(dtype)
 
     @property
     def handle(self):
@@ -174,6 +179,25 @@ class EGNNDynamics(torch.nn.Module):
         _lib.check(L.mcg_egnn_block_debug(self.handle, plan.handle, int(block), _lib.dptr(h), _lib.dptr(x),
                                           _lib.dptr(x0), _lib.current_stream_ptr(self.device)), "mcg_egnn_block_debug")
         return h, x
+
+    def gcl_debug(self, plan: BatchPlan, layer: int, h: torch.Tensor, x: torch.Tensor, x0: torch.Tensor):
+        """One GCL layer (egnn.py:70-85; layer = 2 * block + {0, 1}) on compact arrays, returning the plan's internal
+        buffers: h_out [M,420], pab [M,864] (first edge layer per node: Wa h + b1 | Wb h), agg [M,420],
+        hidden [M,420] (SiLU of the node MLP's first layer) - kernel-level parity pins."""
+        L = _lib.lib()
+        f32 = dict(device=self.device, dtype=torch.float32)
+        M = plan.n_real_nodes
+        h, x, x0 = h.to(**f32).contiguous(), x.to(**f32).contiguous(), x0.to(**f32).contiguous()
+        st = _lib.current_stream_ptr(self.device)
+        _lib.check(L.mcg_egnn_gcl_debug(self.handle, plan.handle, int(layer), _lib.dptr(h), _lib.dptr(x), _lib.dptr(x0), st),
+                   "mcg_egnn_gcl_debug")
+        out = {}
+        for name, which, width in (("h_out", 0, 432), ("pab", 1, 864), ("agg", 2, 432), ("hidden", 3, 432)):
+            buf = torch.empty(M, width, **f32)
+            _lib.check(L.mcg_plan_peek(plan.handle, which, _lib.dptr(buf), st), "mcg_plan_peek")
+            out[name] = buf
+        out["h_out"], out["agg"], out["hidden"] = out["h_out"][:, :420], out["agg"][:, :420], out["hidden"][:, :420]
+        return out
 
     def __del__(self):
         try:

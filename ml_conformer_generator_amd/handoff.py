@@ -6,9 +6,10 @@ mol_utils.py:18-57,110-223, standardizer.py).  RDKit's connectivity perception a
 canonical atom order cannot be reproduced bit-for-bit, so this native route is a
 documented substitute (parity unpinned at the RDKit boundary): atoms keep their
 generation order, 1-order connectivity comes from a covalent-radius rule, and
-"valid" is a valence/connectivity proxy.  When RDKit is importable the generator
-uses the reference-identical route in `rdkit_glue.py` instead.
-All tensor work is batched on the device; one D2H copy at the end.
+"valid" is a valence/connectivity proxy.  The tensor halves (decode, distances + I,
+pad 42, lower-triangle bond write-back) follow the reference and are checked against
+`oracle/host_oracle.py`.  All of it runs in two HIP launches (`mcg_handoff`,
+`mcg_bond_writeback`); one D2H copy at the end.
 """
 from __future__ import annotations
 
@@ -19,11 +20,7 @@ import torch
 
 from .config import ATOM_DECODER, ATOMIC_NUMBERS, DIMENSION
 
-# single-bond covalent radii (Angstrom) of the permitted elements (Cordero 2008), by atomic number
-_RCOV = {6: 0.76, 7: 0.71, 8: 0.66, 9: 0.57, 15: 1.07, 16: 1.05, 17: 1.02, 35: 1.20}
-_COV_FACTOR = 1.3          # RDKit DetermineConnectivity's default covFactor
-_MAX_VALENCE = {6: 4, 7: 4, 8: 2, 9: 1, 15: 5, 16: 6, 17: 1, 35: 1}   # N allows a charged 4th bond
-_BOND_VALENCE = (0.0, 1.0, 2.0, 3.0, 1.5)
+_COV_FACTOR = 1.3          # RDKit DetermineConnectivity's default covFactor (radii: csrc/mcg_gcn.hip k_handoff)
 
 
 @dataclass
@@ -63,44 +60,10 @@ class GeneratedMolecule:
         return "\n".join(lines) + "\n"
 
 
-def decode_samples(x: torch.Tensor, h: torch.Tensor, n_nodes: torch.Tensor):
-    """Atomic numbers [B,N] (0 on padded slots) from the one-hot classes (mol_utils.py:41-45)."""
-    dev = x.device
-    table = torch.tensor(ATOMIC_NUMBERS, device=dev, dtype=torch.long)
-    cls = torch.argmax(h, dim=2)
-    real = torch.arange(x.shape[1], device=dev).unsqueeze(0) < n_nodes.to(dev).unsqueeze(1)
-    return table[cls] * real, real
-
-
-def prepare_adj_mat_seer_input_native(x: torch.Tensor, h: torch.Tensor, n_nodes: torch.Tensor,
-                                      dimension: int = DIMENSION):
-    """elements[B,42] i64, dist_mat[B,42,42] (+I, zero padded), adj_mat[B,42,42] {0,1} (+I)
-    - the tensors `prepare_adj_mat_seer_input` (mol_utils.py:146-194) builds, batched on device."""
-    B, N, _ = x.shape
-    dev = x.device
-    z, real = decode_samples(x, h, n_nodes)
-    elements = torch.zeros(B, dimension, dtype=torch.long, device=dev)
-    elements[:, :N] = z
-    xp = torch.zeros(B, dimension, 3, device=dev, dtype=torch.float32)
-    xp[:, :N] = x * real.unsqueeze(2)
-    realp = torch.zeros(B, dimension, dtype=torch.bool, device=dev)
-    realp[:, :N] = real
-    pair = realp.unsqueeze(1) & realp.unsqueeze(2)
-    d = torch.sqrt(((xp.unsqueeze(2) - xp.unsqueeze(1)) ** 2).sum(-1)) * pair
-    eye = torch.eye(dimension, device=dev)
-    dist_mat = d + eye
-    rc = torch.zeros(36, device=dev)
-    for zz, r in _RCOV.items():
-        rc[zz] = r
-    r = rc[elements]
-    conn = (d < _COV_FACTOR * (r.unsqueeze(1) + r.unsqueeze(2))) & pair & (eye == 0)
-    adj_mat = torch.clamp(conn.to(torch.float32) + eye, max=1.0)
-    return elements, dist_mat, adj_mat
-
-
 def prepare_adj_mat_seer_input_hip(x: torch.Tensor, h: torch.Tensor, n_nodes: torch.Tensor,
                                    dimension: int = DIMENSION):
-    """Same tensors as `prepare_adj_mat_seer_input_native`, built by ONE HIP launch (`mcg_handoff`)."""
+    """elements[B,42] i64, dist_mat[B,42,42] (+I, zero padded), adj_mat[B,42,42] {0,1} (+I) - the tensors
+    `prepare_adj_mat_seer_input` (mol_utils.py:146-194) builds, by ONE HIP launch (`mcg_handoff`)."""
     from . import _lib
     if dimension != DIMENSION:
         raise ValueError("the hand-off kernel is specialised for DIMENSION = 42")
@@ -109,6 +72,8 @@ def prepare_adj_mat_seer_input_hip(x: torch.Tensor, h: torch.Tensor, n_nodes: to
     el = torch.empty(B, dimension, dtype=torch.long, device=dev)
     dm = torch.empty(B, dimension, dimension, dtype=torch.float32, device=dev)
     am = torch.empty(B, dimension, dimension, dtype=torch.float32, device=dev)
+    if B == 0:
+        return el, dm, am
     nn = n_nodes.to(dev, torch.int32).contiguous()
     _lib.check(_lib.lib().mcg_handoff(_lib.dptr(x.contiguous()), _lib.dptr(h.to(torch.float32).contiguous()), _lib.dptr(nn),
                                       B, N, _COV_FACTOR, _lib.dptr(el), _lib.dptr(dm), _lib.dptr(am),
@@ -116,71 +81,42 @@ def prepare_adj_mat_seer_input_hip(x: torch.Tensor, h: torch.Tensor, n_nodes: to
     return el, dm, am
 
 
-def bonds_lower_triangle(bond: torch.Tensor) -> torch.Tensor:
-    """`redefine_bonds` reduction (mol_utils.py:210-211): keep the strict lower triangle of the
-    argmax, then symmetrise it for the record."""
-    low = torch.tril(bond.to(torch.int8), diagonal=-1)
-    return low + low.transpose(-1, -2)
+def bond_writeback_hip(bond: torch.Tensor, elements: torch.Tensor, n_nodes: torch.Tensor
+                       ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(bond_sym [B,42,42] int8, valid_proxy [B] bool) by ONE HIP launch (`mcg_bond_writeback`): the strict lower
+    triangle of the GCN's bond argmax mirrored (`redefine_bonds`, mol_utils.py:210-211) and the valence /
+    single-fragment pre-filter that stands in for `standardize_mol(...) is not None` (a labelled proxy)."""
+    from . import _lib
+    B = int(bond.shape[0])
+    dev = bond.device
+    sym = torch.empty(B, DIMENSION, DIMENSION, dtype=torch.int8, device=dev)
+    valid = torch.empty(B, dtype=torch.uint8, device=dev)
+    if B == 0:
+        return sym, valid.bool()
+    nn = n_nodes.to(dev, torch.int32).contiguous()
+    _lib.check(_lib.lib().mcg_bond_writeback(_lib.dptr(bond.to(torch.int8).contiguous()), _lib.dptr(elements.contiguous()),
+                                             _lib.dptr(nn), B, _lib.dptr(sym), _lib.dptr(valid),
+                                             _lib.current_stream_ptr(dev)), "mcg_bond_writeback")
+    return sym, valid.bool()
 
 
-def valence_proxy_valid(atomic_numbers: torch.Tensor, bonds: torch.Tensor, n: int) -> bool:
-    """Native stand-in for 'standardize_mol(...) is not None' (standardizer.py:83-111):
-    single connected fragment and no atom above its maximum valence.  ALWAYS labelled as a
-    proxy in benchmark output; it is not RDKit sanitisation."""
-    if n == 0:
-        return False
-    b = bonds[:n, :n].to(torch.long)
-    val = torch.tensor(_BOND_VALENCE)[b].sum(1)
-    maxv = torch.tensor([_MAX_VALENCE.get(int(z), 0) for z in atomic_numbers[:n]], dtype=torch.float32)
-    if bool((val > maxv + 1e-6).any()):
-        return False
-    # connectivity by boolean closure (n <= 42)
-    adj = (b > 0) | torch.eye(n, dtype=torch.bool)
-    reach = adj[0].clone()
-    for _ in range(n):
-        new = (adj[reach].any(0)) | reach
-        if bool((new == reach).all()):
-            break
-        reach = new
-    return bool(reach.all())
-
-
-def valence_proxy_valid_batch(elements: torch.Tensor, bonds: torch.Tensor, n_nodes: torch.Tensor) -> torch.Tensor:
-    """`valence_proxy_valid` for a whole batch as tensor algebra (any device): elements [B,D] atomic numbers,
-    bonds [B,D,D] symmetric bond orders, n_nodes [B] -> bool [B].  Connectivity is the boolean closure of
-    (bond > 0) | I by repeated squaring (6 squarings cover paths up to 64 atoms)."""
-    B, D = elements.shape
-    dev = elements.device
-    real = torch.arange(D, device=dev).unsqueeze(0) < n_nodes.to(dev).reshape(B, 1)
-    pair = real.unsqueeze(1) & real.unsqueeze(2)
-    b = bonds.to(torch.long) * pair
-    val = torch.tensor(_BOND_VALENCE, device=dev)[b].sum(2)
-    maxv_table = torch.zeros(36, device=dev)
-    for z, v in _MAX_VALENCE.items():
-        maxv_table[z] = float(v)
-    maxv = maxv_table[elements.clamp(0, 35)]
-    valence_ok = ~(((val > maxv + 1e-6) & real).any(1))
-    adj = (((b > 0) | torch.eye(D, dtype=torch.bool, device=dev).unsqueeze(0)) & pair).to(torch.float32)
-    reach = adj
-    for _ in range(6):
-        reach = (torch.bmm(reach, reach) > 0).to(torch.float32)
-    connected = ((reach[:, 0, :] > 0) | ~real).all(1)
-    return valence_ok & connected & (n_nodes.to(dev).reshape(B) > 0)
+def molecules_from_tensors(x: torch.Tensor, elements: torch.Tensor, bond_sym: torch.Tensor, n_nodes: torch.Tensor,
+                           valid: torch.Tensor) -> List[GeneratedMolecule]:
+    """Slicing-only host pass over (already gathered) result tensors: ONE D2H copy per tensor."""
+    xc, ec, bc, nc, vc = x.cpu(), elements.cpu(), bond_sym.cpu(), n_nodes.cpu(), valid.cpu()
+    out = []
+    for b in range(xc.shape[0]):
+        n = int(nc[b])
+        mol = GeneratedMolecule([int(v) for v in ec[b, :n].tolist()], xc[b, :n].clone(), bc[b, :n, :n].clone())
+        mol.valid = bool(vc[b])
+        out.append(mol)
+    return out
 
 
 def assemble_molecules(x: torch.Tensor, elements: torch.Tensor, bond: torch.Tensor, n_nodes: torch.Tensor
                        ) -> List[GeneratedMolecule]:
-    """Batched bond write-back + validity proxy on the tensors' device, ONE D2H copy of (x, elements, bonds,
-    valid), then a slicing-only host pass (the reference standardises one molecule at a time,
+    """Bond write-back + validity proxy on the device (one launch), ONE D2H copy of (x, elements, bonds, valid),
+    then a slicing-only host pass (the reference standardises one molecule at a time,
     conformer_generator.py:362-366)."""
-    low = torch.tril(bond.to(torch.int8), diagonal=-1)
-    sym = low + low.transpose(-1, -2)                                    # mol_utils.py:210-211
-    valid = valence_proxy_valid_batch(elements, sym, n_nodes)
-    xc, ec, bc, nc, vc = x.cpu(), elements.cpu(), sym.cpu(), n_nodes.cpu(), valid.cpu()
-    out = []
-    for b in range(xc.shape[0]):
-        n = int(nc[b])
-        mol = GeneratedMolecule(ec[b, :n].tolist(), xc[b, :n].clone(), bc[b, :n, :n].clone())
-        mol.valid = bool(vc[b])
-        out.append(mol)
-    return out
+    sym, valid = bond_writeback_hip(bond, elements, n_nodes)
+    return molecules_from_tensors(x, elements, sym, n_nodes, valid)

@@ -31,11 +31,17 @@ def prepare_masks(n_nodes: torch.Tensor, max_n_nodes: int, device) -> Tuple[torc
 
 
 def prepare_edm_input(n_samples: int, reference_context: torch.Tensor, context_norms: Dict[str, torch.Tensor],
-                      min_n_nodes: int, max_n_nodes: int, device):
+                      min_n_nodes: int, max_n_nodes: int, device, sizes: torch.Tensor = None):
     """mol_utils.py:255-295.  Molecule sizes come from the CPU global RNG
     (`torch.randint`), exactly like the reference, so `torch.manual_seed` gives
-    identical size draws."""
-    sizes = torch.randint(min_n_nodes, max_n_nodes + 1, (n_samples,))
+    identical size draws.  `sizes` (optional, [n_samples] integers in [min, max]) hands in sizes drawn
+    elsewhere - the sharded path draws the global vector once and gives every rank its slice."""
+    if sizes is None:
+        sizes = torch.randint(min_n_nodes, max_n_nodes + 1, (n_samples,))
+    else:
+        sizes = sizes.reshape(-1).to("cpu", torch.long)
+        if sizes.numel() != n_samples or (n_samples and (int(sizes.min()) < min_n_nodes or int(sizes.max()) > max_n_nodes)):
+            raise ValueError("sizes must hold n_samples values in [min_n_nodes, max_n_nodes]")
     node_mask, edge_mask = prepare_masks(sizes, max_n_nodes, device)
     normed = ((reference_context.cpu() - context_norms["mean"]) / context_norms["mad"]).to(device)
     ctx = normed.unsqueeze(0).repeat(n_samples, 1).unsqueeze(1).repeat(1, max_n_nodes, 1) * node_mask
@@ -176,3 +182,26 @@ def ifm_prepare_fragments_for_merge(fixed_fragment_x, fixed_fragment_h, gen_frag
     fixed_mask = torch.zeros((B, max_n_nodes, 1), dtype=torch.float32, device=device)
     fixed_mask[:, :n_ff, 0] = 1.0
     return torch.cat([x, h], dim=2), fixed_mask
+
+
+def ifm_merge_hip(fixed_fragment_x, fixed_fragment_h, gen_fragments_x, gen_fragments_h, shift, rotation, device,
+                  max_n_nodes: int):
+    """`inverse_coord_transform` + `ifm_prepare_fragments_for_merge` (mol_utils.py:508-524, :460-505) as ONE HIP
+    launch (`mcg_ifm_merge`) on the first sampler run's device outputs: z_known [B,N,11], fixed_mask [B,N,1]."""
+    from . import _lib
+    f32 = dict(device=device, dtype=torch.float32)
+    ffx = fixed_fragment_x.to(**f32).contiguous()
+    ffh = fixed_fragment_h.to(**f32).contiguous()
+    gx = gen_fragments_x.to(**f32).contiguous()
+    gh = gen_fragments_h.to(**f32).contiguous()
+    sh = shift.to(**f32).contiguous()
+    rot = rotation.to(**f32).contiguous()
+    B, n_gen, n_ff = int(gx.shape[0]), int(gx.shape[1]), int(ffx.shape[0])
+    if n_ff + n_gen != max_n_nodes:
+        raise ValueError("fixed fragment + generated fragment rows must fill max_n_nodes")
+    z_known = torch.empty((B, max_n_nodes, 3 + ffh.shape[1]), **f32)
+    fixed_mask = torch.empty((B, max_n_nodes, 1), **f32)
+    _lib.check(_lib.lib().mcg_ifm_merge(_lib.dptr(ffx), _lib.dptr(ffh), n_ff, _lib.dptr(gx), _lib.dptr(gh), n_gen,
+                                        _lib.dptr(sh), _lib.dptr(rot), B, max_n_nodes, _lib.dptr(z_known),
+                                        _lib.dptr(fixed_mask), _lib.current_stream_ptr(torch.device(device))), "mcg_ifm_merge")
+    return z_known, fixed_mask

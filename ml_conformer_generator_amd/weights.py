@@ -106,12 +106,51 @@ def synth_state_dict(spec: Spec, seed: int, coord_out_gain: float = 0.05,
     return out
 
 
-def synth_edm_state_dict(seed: int = 1234, weight_gain: float = 0.3, **kw) -> Dict[str, torch.Tensor]:
-    """weight_gain 0.3: an UNTRAINED denoiser cannot cancel the 1/alpha_ts growth of
-    the ancestral update, so |z| reaches 1e3..1e5 along a synthetic trajectory; a
-    contractive gain keeps every activation finite in fp32 (probed: gain 1.0
-    overflows to NaN once |x| ~ 1e3)."""
-    sd = synth_state_dict(edm_spec(), seed, weight_gain=weight_gain, **kw)
+# Per-tensor gains of the default synthetic EGNN weights ("v2").  Chosen with tools/parity_sensitivity.py so that
+# every golden fixture can SEE the arithmetic it pins: Linear layers variance-preserving (gain sqrt(3) ~ 1.7 on the
+# nn.Linear U(+-1/sqrt(fan_in)) family, instead of a contractive 0.3 under which messages were ~1e-2 of h), attention
+# weights large enough that the gate actually varies over edges, the aggregated-message half of the node MLP's first
+# layer boosted against the /100 normalisation, and a small output layer / coordinate head so that an UNTRAINED
+# denoiser does not blow the ancestral sampler up (|z| still reaches ~1e3 through the 1/alpha_ts growth, finite in
+# fp32 in the reference itself).
+RECIPE_V2 = dict(linear=1.7, att=4.0, att_bias=10.0, agg=4.0, node_out=0.5, embed_out=0.3, coord_out=0.05, dist=1.0)
+# "v2d": the same with the two squared-distance columns of every edge / coordinate MLP damped.  Fixtures whose
+# trajectory passes through |x| ~ 1e3 (resampling and inpainting repeat the 1/alpha_ts amplification of the first
+# step) need it: the untrained coordinate head otherwise feeds x -> d^2 ~ x^2 -> x back on itself and overflows fp32
+# (in the reference too; a trained head keeps phi small).
+RECIPES = {"v2": RECIPE_V2, "v2d": dict(RECIPE_V2, dist=0.02)}
+
+
+def synth_edm_state_dict(seed: int = 1234, weight_gain: float = None, recipe: str = "v2", **kw) -> Dict[str, torch.Tensor]:
+    """Deterministic synthetic EGNN weights in the reference's checkpoint layout.
+    Default: the "v2" recipe above.  `weight_gain=g` (legacy form): one uniform gain on every Linear tensor."""
+    if weight_gain is not None:
+        sd = synth_state_dict(edm_spec(), seed, weight_gain=weight_gain, **kw)
+    else:
+        if recipe not in RECIPES:
+            raise ValueError(f"unknown synthetic weight recipe {recipe!r}")
+        r = RECIPES[recipe]
+        sd = synth_state_dict(edm_spec(), seed, weight_gain=1.0, coord_out_gain=kw.pop("coord_out_gain", r["coord_out"]), **kw)
+        H = EGNN_HIDDEN
+        for k, v in sd.items():
+            if k.endswith("att_mlp.0.weight"):
+                v *= r["att"]
+            elif k.endswith("att_mlp.0.bias"):
+                v *= r["att_bias"]
+            elif k.endswith("node_mlp.0.weight"):
+                v *= r["linear"]
+                v[:, H:] *= r["agg"]
+            elif k.endswith("node_mlp.2.weight"):
+                v *= r["node_out"]
+            elif k.endswith("embedding_out.weight"):
+                v *= r["embed_out"]
+            elif k.endswith("coord_mlp.4.weight"):
+                pass
+            elif k.endswith("edge_mlp.0.weight") or k.endswith("coord_mlp.0.weight"):
+                v *= r["linear"]
+                v[:, 2 * H:] *= r["dist"]
+            elif k.endswith(".weight"):
+                v *= r["linear"]
     # The checkpoint also carries the training-time 1000-step schedule
     # (`gamma.gamma`, length 1001); it is replaced right after loading
     # (conformer_generator.py:105-113) so only its presence/shape matters.

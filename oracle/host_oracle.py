@@ -69,3 +69,103 @@ def fragment_latent(coord: torch.Tensor, one_hot: torch.Tensor, n_samples: int,
     fixed = torch.zeros((n_samples, max_n_nodes, 1), dtype=torch.float32)
     fixed[:, :n, 0] = 1.0
     return z_known, fixed
+
+
+# ------------------------------------------------------------------------------------------------
+# EDM -> GCN hand-off, bond write-back and the tensor work between the two sampler runs of inertial
+# fragment matching.  The RDKit-owned decisions inside these
+# reference functions cannot run here; each substitute is named where it is made.
+# ------------------------------------------------------------------------------------------------
+_ATOM_DECODER = {0: "C", 1: "N", 2: "O", 3: "F", 4: "P", 5: "S", 6: "Cl", 7: "Br"}          # utils/config.py:9-18
+_ATOMIC_NUMBER = {"C": 6, "N": 7, "O": 8, "F": 9, "P": 15, "S": 16, "Cl": 17, "Br": 35}
+# single-bond covalent radii (Angstrom, Cordero 2008) - the radii table of the connectivity SUBSTITUTE below
+_RCOV = {6: 0.76, 7: 0.71, 8: 0.66, 9: 0.57, 15: 1.07, 16: 1.05, 17: 1.02, 35: 1.20}
+_MAX_VALENCE = {6: 4, 7: 4, 8: 2, 9: 1, 15: 5, 16: 6, 17: 1, 35: 1}
+_BOND_VALENCE2 = (0, 2, 4, 6, 3)          # twice the valence of bond classes none / 1 / 2 / 3 / aromatic
+
+
+def adj_mat_seer_input(positions: torch.Tensor, one_hot: torch.Tensor, n_nodes: torch.Tensor, dimension: int = 42,
+                       cov_factor: float = 1.3):
+    """Tensor half of `samples_to_rdkit_mol` (mol_utils.py:18-57) + `prepare_adj_mat_seer_input` (:146-194),
+    one molecule at a time like the reference:
+      * atoms = argmax(one_hot) -> element symbol (:41-45); the coordinates travel through the XYZ text block
+        written with "%.9f" (:46-51) and come back as DOUBLES (`torch.tensor(conf.GetPositions())`, :171);
+      * elements = atomic numbers, zero padded (`MolGraph.elements_vector`, molgraph.py:224-234);
+      * dist_mat = fp64 `distance_matrix` (:129-143), zero padded to `dimension`, + I, stored into the fp32
+        batch tensor (:178-187);
+      * adj_mat = (1-order connectivity > 0) + I clamped to {0, 1} (:175-180).
+    SUBSTITUTES (parity unpinned, RDKit absent): the connectivity is the covalent-radius rule
+    d_ij < cov_factor * (r_i + r_j) that RDKit's `DetermineConnectivity` documents (instead of the RDKit call,
+    :117), and atoms keep their generation order (instead of the canonical SMILES order, :118-124)."""
+    B = positions.size(0)
+    elements = torch.zeros(B, dimension, dtype=torch.long)
+    dist_b = torch.zeros(B, dimension, dimension)
+    adj_b = torch.zeros(B, dimension, dimension)
+    for b in range(B):
+        n = int(n_nodes[b])
+        atoms = torch.argmax(one_hot[b], dim=1)
+        z = [_ATOMIC_NUMBER[_ATOM_DECODER[int(atoms[i])]] for i in range(n)]
+        coord = torch.tensor([[float("%.9f" % float(positions[b, i, k])) for k in range(3)] for i in range(n)],
+                             dtype=torch.float64).reshape(n, 3)
+        dist = pairwise_distance(coord)
+        pad = torch.nn.functional.pad(dist, (0, dimension - n, 0, dimension - n), "constant", 0) + torch.eye(dimension)
+        r = torch.tensor([_RCOV[v] for v in z], dtype=torch.float64)
+        conn = (dist < cov_factor * (r.unsqueeze(0) + r.unsqueeze(1))) & ~torch.eye(n, dtype=torch.bool)
+        sc = torch.zeros(dimension, dimension)
+        sc[:n, :n] = conn.float()
+        sc = sc + torch.eye(dimension)
+        sc[sc > 0] = 1
+        elements[b, :n] = torch.tensor(z, dtype=torch.long)
+        dist_b[b] = pad                     # fp64 -> fp32 on assignment, as in the reference
+        adj_b[b] = sc
+    return elements, dist_b, adj_b
+
+
+def bond_writeback(bond_argmax: torch.Tensor, elements: torch.Tensor, n_nodes: torch.Tensor):
+    """`redefine_bonds` (mol_utils.py:197-223), tensor half: `tril(argmax)` with the diagonal removed (:210-211),
+    one bond (i, j) per non-zero entry with i, j < n (:213-220) - returned mirrored.  Then the validity
+    SUBSTITUTE for `standardize_mol(...) is not None` (conformer_generator.py:362-366; standardizer.py:83-111 is
+    RDKit sanitisation + MMFF): no atom above its maximum valence, one connected fragment.  Plain loops."""
+    B, D, _ = bond_argmax.shape
+    sym = torch.zeros(B, D, D, dtype=torch.int8)
+    valid = torch.zeros(B, dtype=torch.bool)
+    for b in range(B):
+        n = int(n_nodes[b])
+        repr_m = torch.tril(bond_argmax[b].to(torch.long))
+        repr_m = repr_m * (1 - torch.eye(D, dtype=torch.long))
+        nbrs = [[] for _ in range(n)]
+        val2 = [0] * n
+        for i in range(n):
+            for j in range(n):
+                t = int(repr_m[i, j])
+                if t != 0:
+                    sym[b, i, j] = t
+                    sym[b, j, i] = t
+                    nbrs[i].append(j); nbrs[j].append(i)
+                    val2[i] += _BOND_VALENCE2[t]; val2[j] += _BOND_VALENCE2[t]
+        if n == 0:
+            continue
+        ok = all(val2[i] <= 2 * _MAX_VALENCE.get(int(elements[b, i]), 0) for i in range(n))
+        seen, stack = {0}, [0]
+        while stack:
+            for j in nbrs[stack.pop()]:
+                if j not in seen:
+                    seen.add(j); stack.append(j)
+        valid[b] = ok and len(seen) == n
+    return sym, valid
+
+
+def ifm_merge_input(fixed_fragment_x: torch.Tensor, fixed_fragment_h: torch.Tensor, gen_fragments_x: torch.Tensor,
+                    gen_fragments_h: torch.Tensor, shift: torch.Tensor, rotation: torch.Tensor, max_n_nodes: int):
+    """`inverse_coord_transform` (mol_utils.py:508-524: bmm with the transposed rotation, then minus the shift)
+    followed by `ifm_prepare_fragments_for_merge` (:460-505: fixed fragment first, cat along atoms, cat along
+    channels, fixed_mask on the first n_ff rows)."""
+    B = gen_fragments_x.size(0)
+    x_rot = torch.bmm(gen_fragments_x, torch.transpose(rotation, 1, 2)) - shift.view(B, 1, 3)
+    n_ff = fixed_fragment_x.size(0)
+    x_prep = torch.cat([fixed_fragment_x.unsqueeze(0).repeat(B, 1, 1), x_rot], dim=1)
+    h_prep = torch.cat([fixed_fragment_h.unsqueeze(0).repeat(B, 1, 1), gen_fragments_h], dim=1)
+    z_known = torch.cat([x_prep, h_prep], dim=2)
+    fixed_mask = torch.zeros((B, max_n_nodes, 1), dtype=torch.float32)
+    fixed_mask[:, :n_ff, 0] = 1.0
+    return z_known, fixed_mask

@@ -30,10 +30,21 @@ def load_golden(name):
     return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fi" and z[k].ndim > 0 else z[k]) for k in z.files}
 
 
+_SD_CACHE = {}
+
+
+def sd_for(g):
+    """The synthetic EGNN weights a golden fixture was generated with (its `weight_seed` / `weight_recipe`)."""
+    from ml_conformer_generator_amd.weights import synth_edm_state_dict
+    key = (int(g["weight_seed"]), str(g["weight_recipe"]) if "weight_recipe" in g else "v2")
+    if key not in _SD_CACHE:
+        _SD_CACHE[key] = synth_edm_state_dict(key[0], recipe=key[1])
+    return _SD_CACHE[key]
+
+
 @pytest.fixture(scope="session")
 def edm_sd():
-    from ml_conformer_generator_amd.weights import synth_edm_state_dict
-    return synth_edm_state_dict(1234)
+    return sd_for({"weight_seed": 1234, "weight_recipe": "v2"})
 
 
 @pytest.fixture(scope="session")

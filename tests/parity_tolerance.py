@@ -1,0 +1,55 @@
+"""Stated parity tolerances, shared by the GPU parity tests, `__graft_entry__.smoke()` and
+`tools/parity_sensitivity.py` (the committed mutation check that proves these tolerances can SEE the
+arithmetic they guard).
+
+fp32: one network call  |a - b| <= atol * S + rtol * |b|  with rtol 1e-4, atol 1e-5 and S the REAL
+magnitude max|b| of the channel group the element belongs to - velocity / coordinates (channels 0..2) and atom-type
+features (channels 3..) are scaled separately, because they differ by orders of magnitude and a shared (or floored)
+scale would hide errors in the smaller group.  Sampler trajectories under an identical noise tape: 1e-3 * S per step and group.
+"""
+import torch
+
+RTOL, ATOL = 1e-4, 1e-5
+TRAJ_REL = 1e-3
+
+
+def _groups(last_dim, split):
+    if split is None or last_dim <= split:
+        return [slice(0, last_dim)]
+    return [slice(0, split), slice(split, last_dim)]
+
+
+def violation(a, b, rtol=RTOL, atol=ATOL, split=None):
+    """max over elements of |a - b| / (atol * S_group + rtol * |b|); <= 1 means within tolerance.
+    `split`: channel index separating the two groups of the LAST dimension (3 for [.., 11] tensors)."""
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    worst = 0.0
+    for sl in _groups(b.shape[-1], split):
+        aa, bb = a[..., sl], b[..., sl]
+        scale = float(bb.abs().max())
+        if scale == 0.0:
+            worst = max(worst, 0.0 if float(aa.abs().max()) == 0.0 else float("inf"))
+            continue
+        worst = max(worst, float(((aa - bb).abs() / (atol * scale + rtol * bb.abs())).max()))
+    return worst
+
+
+def close(a, b, rtol=RTOL, atol=ATOL, split=None):
+    """(ok, max abs error, scale of the reference) under the stated per-call tolerance."""
+    v = violation(a, b, rtol, atol, split)
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return v <= 1.0, float((a - b).abs().max()), float(b.abs().max())
+
+
+def traj_violation(a, b, rel=TRAJ_REL, split=3):
+    """Sampler trajectories [steps, B, N, C]: max over steps and channel groups of |a - b| / (rel * S), S = the
+    magnitude of that step's group in the reference (|z| moves over orders of magnitude along a trajectory: one
+    global scale would hide the small steps behind the largest)."""
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    worst = 0.0
+    for s in range(b.shape[0]):
+        for sl in _groups(b.shape[-1], split):
+            scale = float(b[s][..., sl].abs().max())
+            if scale > 0:
+                worst = max(worst, float((a[s][..., sl] - b[s][..., sl]).abs().max()) / (rel * scale))
+    return worst

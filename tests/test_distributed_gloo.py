@@ -6,7 +6,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from ml_conformer_generator_amd.distributed import gather_results, rank_seed, shard_range, shard_sizes
+from ml_conformer_generator_amd.distributed import (draw_global_sizes, gather_results, rank_seed, shard_range,
+                                                    shard_sizes, sharded_generate)
 
 
 def test_shard_ranges_cover_the_batch():
@@ -60,3 +61,103 @@ def test_gather_results_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The REAL shard path: `MLConformerGenerator.generate_conformers_sharded` -> `distributed.sharded_generate`
+# (global size vector drawn once on rank 0 + broadcast, contiguous slices, per-rank noise seed, one gather),
+# with only the device work (`_generate_shard`: sampler + GCN kernels) replaced by a stub.
+# ---------------------------------------------------------------------------------------------------------
+def _shell_generator():
+    """An MLConformerGenerator without its constructor (which needs the GPU): just the attributes the shard
+    path reads."""
+    from ml_conformer_generator_amd.conformer_generator import MLConformerGenerator
+    gen = MLConformerGenerator.__new__(MLConformerGenerator)
+    torch.nn.Module.__init__(gen)
+    gen.device = torch.device("cpu")
+    gen.dimension = 42
+    gen.min_n_nodes, gen.max_n_nodes = 15, 39
+    gen.last_batch = gen.last_valid_fraction = gen._timing = None
+    return gen
+
+
+def _stub_shard(calls):
+    def run(ref_context, ref_n_atoms, variance, sizes, n_samples, *rest):
+        calls.append((sizes.clone(), n_samples))
+        N, D = min(ref_n_atoms + variance, 39), 42
+        el = torch.zeros(n_samples, D, dtype=torch.int8)
+        for b in range(n_samples):
+            el[b, : int(sizes[b])] = 6
+        # x encodes the molecule size so the gathered order can be checked; odd sizes are "invalid"
+        x = sizes.float().view(-1, 1, 1).repeat(1, N, 3)
+        return dict(x=x, elements=el, bond=torch.zeros(n_samples, D, D, dtype=torch.int8),
+                    n_nodes=sizes.to(torch.int32), valid=(sizes % 2 == 0).to(torch.uint8))
+    return run
+
+
+def _shard_worker(rank, world, port, n_samples, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(1000 + 17 * rank)            # ranks disagree on purpose: only rank 0's draw may count
+    gen = _shell_generator()
+    calls = []
+    gen._generate_shard = _stub_shard(calls)
+    mols = gen.generate_conformers_sharded(reference_context=torch.tensor([50.0, 100.0, 130.0]), n_atoms=27, variance=12,
+                                           n_samples=n_samples)
+    # what a single process seeded like rank 0 draws (the reference's draw, mol_utils.py:275)
+    torch.manual_seed(1000)
+    expect = torch.randint(15, 40, (n_samples,))
+    lo, hi = shard_range(n_samples, rank, world)
+    ok = len(calls) == 1 and torch.equal(calls[0][0], expect[lo:hi]) and calls[0][1] == hi - lo
+    ok = ok and [m.GetNumAtoms() for m in mols] == [int(v) for v in expect.tolist() if v % 2 == 0]
+    ok = ok and all(float(m.coords[0, 0]) == m.GetNumAtoms() for m in mols)
+    ok = ok and abs(gen.last_valid_fraction - float((expect % 2 == 0).float().mean())) < 1e-6
+    # the generic entry: per-rank noise seeds and an EMPTY shard (1 sample, 2 ranks)
+    seeds = []
+    _, full = sharded_generate(1, lambda: draw_global_sizes(1, 20, 20), lambda sz, lo_, hi_: {"v": sz.float()},
+                               seed=7, seed_fn=seeds.append)
+    ok = ok and seeds == [rank_seed(7, rank)] and full["v"].tolist() == [20.0]
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_generate_conformers_sharded_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, 11, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_sharded_path_without_a_process_group_is_the_plain_call():
+    torch.manual_seed(5)
+    expect = torch.randint(25, 30, (6,))
+    torch.manual_seed(5)
+    gen = _shell_generator()
+    calls = []
+    gen._generate_shard = _stub_shard(calls)
+    mols = gen.generate_conformers_sharded(reference_context=torch.tensor([50.0, 100.0, 130.0]), n_atoms=27, variance=2,
+                                           n_samples=6)
+    assert torch.equal(calls[0][0], expect) and len(mols) == int((expect % 2 == 0).sum())
+
+
+def test_bench_refuses_to_report_fewer_gpus_than_asked():
+    """`python bench.py --gpus 2` must start 2 ranks itself or fail: on a box with fewer than 2 GPUs (this
+    container has none) it exits non-zero and prints no JSON line (never `n_gpus: 1`)."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    if torch.cuda.device_count() >= 2:
+        return                      # a real multi-GPU box: the run itself is the driver's SCALE check
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert '"n_gpus"' not in r.stdout

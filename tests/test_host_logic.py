@@ -2,16 +2,17 @@
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 
+from conftest import GOLDEN as GOLD
 from conftest import REPO, load_golden
 from ml_conformer_generator_amd import config as C
 from ml_conformer_generator_amd import mol_utils as MU
 from ml_conformer_generator_amd import schedule as S
 from ml_conformer_generator_amd import weights as W
-from ml_conformer_generator_amd.handoff import (GeneratedMolecule, bonds_lower_triangle,
-                                                prepare_adj_mat_seer_input_native, valence_proxy_valid)
+from ml_conformer_generator_amd.handoff import GeneratedMolecule
 from oracle import diffusion_oracle as DO
 from oracle import host_oracle as HO
 
@@ -98,29 +99,39 @@ def test_step_scalars_match_oracle_expressions():
         assert float(got[0]) == float(a_ts)
 
 
-def test_native_handoff_shapes_and_proxy():
+def test_handoff_oracle_shapes_and_proxy_rules():
+    """The oracle's restatement of the hand-off tensors (mol_utils.py:146-194) and of the bond write-back + validity
+    substitute (mol_utils.py:197-223) on hand-made cases; the HIP kernels are compared with it in the GPU tests."""
+    from oracle import host_oracle as HO
     torch.manual_seed(0)
     B, N = 3, 19
     n_nodes = torch.tensor([15, 19, 17])
     x = torch.randn(B, N, 3) * 2
     h = torch.nn.functional.one_hot(torch.randint(0, 7, (B, N)), 8).float()
-    el, dm, am = prepare_adj_mat_seer_input_native(x, h, n_nodes)
+    el, dm, am = HO.adj_mat_seer_input(x, h, n_nodes)
     assert el.shape == (B, 42) and dm.shape == (B, 42, 42) and am.shape == (B, 42, 42)
+    assert dm.dtype == torch.float32 and el.dtype == torch.long
     assert int((el[0, 15:] != 0).sum()) == 0 and set(el[1, :19].tolist()) <= set(C.ATOMIC_NUMBERS)
     assert torch.equal(dm, dm.transpose(1, 2)) and torch.equal(am, am.transpose(1, 2))
     assert float(torch.diagonal(dm, dim1=1, dim2=2).min()) == 1.0 and float(am.max()) == 1.0
     assert float(dm[0, 15:, :].abs().sum() - (42 - 15)) == 0.0            # only the +I survives on padding
     # ethane-like: two carbons, one single bond -> valid; a carbon with 5 bonds -> invalid
-    z = torch.tensor([6, 6] + [0] * 40)
-    bonds = torch.zeros(42, 42, dtype=torch.int8)
-    bonds[1, 0] = 1
-    assert valence_proxy_valid(z, bonds_lower_triangle(bonds), 2)
-    z5 = torch.tensor([6] * 6 + [0] * 36)
-    b5 = torch.zeros(42, 42, dtype=torch.int8)
-    b5[1:6, 0] = 1
-    assert not valence_proxy_valid(z5, bonds_lower_triangle(b5), 6)
-    bd = torch.zeros(42, 42, dtype=torch.int8)                             # two disconnected atoms
-    assert not valence_proxy_valid(z, bd, 2)
+    z = torch.tensor([[6, 6] + [0] * 40])
+    bonds = torch.zeros(1, 42, 42, dtype=torch.int8)
+    bonds[0, 1, 0] = 1
+    bonds[0, 0, 1] = 3                       # upper triangle is ignored (tril, mol_utils.py:210)
+    sym, ok = HO.bond_writeback(bonds, z, torch.tensor([2]))
+    assert bool(ok[0]) and int(sym[0, 0, 1]) == 1 and int(sym[0, 1, 0]) == 1
+    z5 = torch.tensor([[6] * 6 + [0] * 36])
+    b5 = torch.zeros(1, 42, 42, dtype=torch.int8)
+    b5[0, 1:6, 0] = 1
+    assert not bool(HO.bond_writeback(b5, z5, torch.tensor([6]))[1][0])
+    bd = torch.zeros(1, 42, 42, dtype=torch.int8)                             # two disconnected atoms
+    assert not bool(HO.bond_writeback(bd, z, torch.tensor([2]))[1][0])
+    ar = torch.zeros(1, 42, 42, dtype=torch.int8)                             # aromatic bonds count 1.5: 2 on O is too many
+    ar[0, 1, 0] = 4; ar[0, 2, 1] = 4
+    assert not bool(HO.bond_writeback(ar, torch.tensor([[6, 8, 6] + [0] * 39]), torch.tensor([3]))[1][0])
+    assert bool(HO.bond_writeback(ar, torch.tensor([[6, 6, 6] + [0] * 39]), torch.tensor([3]))[1][0])
     m = GeneratedMolecule([6, 8], torch.zeros(2, 3), torch.zeros(2, 2, dtype=torch.int8))
     assert m.symbols == ["C", "O"] and m.to_xyz_block().startswith("2\n\nC 0.000000000")
     bo = torch.tensor([[0, 2, 0], [2, 0, 1], [0, 1, 0]], dtype=torch.int8)
@@ -187,32 +198,14 @@ def test_batched_principal_frames_match_reference_on_cpu_tensors():
         assert float(frames[i, nn[i]:].abs().max() if nn[i] < N else 0.0) == 0.0
 
 
-def test_batched_validity_proxy_equals_scalar_proxy():
-    """`valence_proxy_valid_batch` (tensor algebra, used by assemble_molecules) against the per-molecule
-    `valence_proxy_valid` on chains with random extra bonds, broken chains (disconnected) and over-valent atoms."""
-    from ml_conformer_generator_amd.handoff import (assemble_molecules, bonds_lower_triangle, valence_proxy_valid,
-                                                    valence_proxy_valid_batch)
-    g = torch.Generator().manual_seed(5)
-    B, D = 64, 42
-    n = torch.randint(3, 40, (B,), generator=g)
-    el = torch.zeros(B, D, dtype=torch.long)
-    bond = torch.zeros(B, D, D, dtype=torch.int8)
-    for b in range(B):
-        nn = int(n[b])
-        el[b, :nn] = torch.tensor([6, 6, 6, 7, 8])[torch.randint(0, 5, (nn,), generator=g)]
-        for i in range(1, nn):
-            if b % 4 != 1 or i != nn // 2:                       # every 4th molecule gets a broken chain
-                bond[b, i, i - 1] = 1
-        if b % 4 == 2:                                           # over-valent: a triple + double bond on one atom
-            bond[b, 1, 0] = 3
-            bond[b, 2, 1] = 2
-        if b % 4 == 3 and nn > 6:                                # ring closure
-            bond[b, 5, 0] = 1
-    sym = torch.stack([bonds_lower_triangle(bond[b]) for b in range(B)])
-    batch = valence_proxy_valid_batch(el, sym, n)
-    scalar = [valence_proxy_valid(el[b], sym[b], int(n[b])) for b in range(B)]
-    assert batch.tolist() == scalar
-    assert 10 < sum(scalar) < B - 10                              # the cases above really split both ways
-    mols = assemble_molecules(torch.randn(B, D, 3), el, bond, n)
-    assert [m.valid for m in mols] == scalar
-    assert all(m.bond_orders.shape == (int(n[b]), int(n[b])) for b, m in enumerate(mols))
+def test_ifm_merge_oracle_matches_reference_golden():
+    """oracle.ifm_merge_input (inverse_coord_transform + ifm_prepare_fragments_for_merge, mol_utils.py:460-524)
+    against the reference's own outputs."""
+    from oracle import host_oracle as HO
+    g = np.load(os.path.join(GOLD, "ifm_front_end.npz"))
+    fx = torch.tensor(g["frag_x"])
+    fh = MU.one_hot_classes(g["frag_z"].tolist()).float()
+    zk, fm = HO.ifm_merge_input(fx, fh, torch.tensor(g["xg"]), torch.tensor(g["hg"]), torch.tensor(g["shift"]),
+                                torch.tensor(g["rotation"]), int(g["z_known"].shape[1]))
+    assert torch.equal(fm, torch.tensor(g["fixed_mask"]))
+    assert float((zk - torch.tensor(g["z_known"])).abs().max()) <= 1e-6

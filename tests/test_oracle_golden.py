@@ -4,11 +4,12 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import TapeNoise, load_golden
+from conftest import TapeNoise, load_golden, sd_for
 from oracle import diffusion_oracle as DO
 from oracle import egnn_oracle as EO
 from oracle import gcn_oracle as GO
 from oracle import host_oracle as HO
+from parity_tolerance import traj_violation, violation
 
 torch.set_num_threads(8)
 
@@ -64,49 +65,54 @@ def test_single_block(edm_sd):
     d0, _ = EO.pair_geometry(g["x0"], row, col)
     d1, _ = EO.pair_geometry(g["x_in"], row, col)
     p = "dynamics.egnn.e_block_3."
-    h1, m1, _, _ = EO.gcl(edm_sd, p + "gcl_0.", g["h_in"], row, col, torch.cat([d1, d0], 1), nmf, emf)
+    h1, m1, msg1, agg1 = EO.gcl(edm_sd, p + "gcl_0.", g["h_in"], row, col, torch.cat([d1, d0], 1), nmf, emf)
     assert torch.allclose(h1, g["h_after_gcl0"], rtol=1e-5, atol=1e-6)
     assert torch.allclose(m1[:N], g["m_gcl0_node0"], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(msg1[:N], g["msg_gcl0_node0"], rtol=1e-5, atol=1e-6)      # gate * mask (egnn.py:48-51)
+    assert torch.allclose(agg1, g["agg_gcl0"], rtol=1e-5, atol=1e-6)                # segment sum / 100 (egnn.py:59-64)
+    assert float(g["agg_gcl0"].abs().max()) > 0.05                                  # the aggregate carries real signal
     h, x = EO.equivariant_block(edm_sd, p, g["h_in"], g["x_in"], row, col, nmf, emf, d0)
     assert torch.allclose(h, g["h_out"], rtol=1e-5, atol=1e-6)
     assert torch.allclose(x, g["x_out"], rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("name", ["sampler_T20_b4n19.npz", "sampler_T8_rs1.npz"])
-def test_sampler_trajectory(edm_sd, name):
+def test_sampler_trajectory(name):
     g = load_golden(name)
+    assert bool(torch.isfinite(g["z_trace"]).all())
     nm = g["node_mask"]
-    s = DO.SamplerOracle(edm_sd, int(g["T"]), noise_fn=TapeNoise(g["noise"]))
+    s = DO.SamplerOracle(sd_for(g), int(g["T"]), noise_fn=TapeNoise(g["noise"]))
     s.trace = []
     x, h = s.forward(nm, edge_mask_of(nm), g["context"], int(g["resample_steps"]))
     assert s.noise_fn.pos == g["noise"].numel()          # same number of draws, same order
     zt = torch.stack(s.trace)
-    assert torch.allclose(zt, g["z_trace"], rtol=1e-4, atol=1e-5), float((zt - g["z_trace"]).abs().max())
-    assert torch.allclose(x, g["x"], rtol=1e-4, atol=1e-5)
+    assert traj_violation(zt, g["z_trace"], rel=2e-5) <= 1.0, traj_violation(zt, g["z_trace"], rel=2e-5)
+    assert violation(x, g["x"]) <= 1.0
     assert torch.equal(h.to(torch.int64), g["h"].to(torch.int64))
 
 
-def test_inpaint(edm_sd):
+def test_inpaint():
     g = load_golden("inpaint_T5.npz")
+    assert bool(torch.isfinite(g["z_trace"]).all())
     nm = g["node_mask"]
-    s = DO.SamplerOracle(edm_sd, int(g["T"]), noise_fn=TapeNoise(g["noise"]))
+    s = DO.SamplerOracle(sd_for(g), int(g["T"]), noise_fn=TapeNoise(g["noise"]))
     s.trace = []
     x, h = s.inpaint(nm, edge_mask_of(nm), g["context"], g["z_known"], g["fixed_mask"], 1, 3)
     assert s.noise_fn.pos == g["noise"].numel()
-    assert torch.allclose(torch.stack(s.trace), g["z_trace"], rtol=1e-4, atol=1e-5)
-    assert torch.allclose(x, g["x"], rtol=1e-4, atol=1e-5)
+    assert traj_violation(torch.stack(s.trace), g["z_trace"], rel=2e-5) <= 1.0
+    assert violation(x, g["x"]) <= 1.0
     assert torch.equal(h.to(torch.int64), g["h"].to(torch.int64))
 
 
-def test_merge_fragments(edm_sd):
-    g = load_golden("merge_T10_L4.npz")
+def test_merge_fragments():
+    g = load_golden("merge_T10_L10.npz")
     nm = g["node_mask"]
-    s = DO.SamplerOracle(edm_sd, int(g["T"]), noise_fn=TapeNoise(g["noise"]))
+    s = DO.SamplerOracle(sd_for(g), int(g["T"]), noise_fn=TapeNoise(g["noise"]))
     s.trace = []
-    x, h = s.merge_fragments(nm, edge_mask_of(nm), g["fixed_mask"], g["context"], g["z_known"], 4, 1, 3)
+    x, h = s.merge_fragments(nm, edge_mask_of(nm), g["fixed_mask"], g["context"], g["z_known"], int(g["diffusion_level"]), 1, 3)
     assert s.noise_fn.pos == g["noise"].numel()
-    assert torch.allclose(torch.stack(s.trace), g["z_trace"], rtol=1e-4, atol=1e-5)
-    assert torch.allclose(x, g["x"], rtol=1e-4, atol=1e-5)
+    assert traj_violation(torch.stack(s.trace), g["z_trace"], rel=2e-5) <= 1.0
+    assert violation(x, g["x"]) <= 1.0
     assert torch.equal(h.to(torch.int64), g["h"].to(torch.int64))
     # diffusion_level > T fails exactly like the reference (quirk H5)
     assert str(load_golden("merge_level_gt_T.npz")["error"]) == "IndexError"

@@ -143,7 +143,7 @@ def main():
         t = torch.full((B, 1), 51.0) / 100
         with torch.no_grad():
             out = gm.dynamics(t, z, nm, em, ctx)
-        save(f"dynamics_{tag}.npz", t=t, xh=z, node_mask=nm, context=ctx, out=out, weight_seed=1234)
+        save(f"dynamics_{tag}.npz", t=t, xh=z, node_mask=nm, context=ctx, out=out, weight_seed=1234, weight_recipe=np.array("v2"))
 
     # 4b. a single EquivariantBlock and its GCL internals (a9, a11-a13) - kernel-level pins
     torch.manual_seed(21)
@@ -160,10 +160,14 @@ def main():
         d1, unit = egnn.coord2diff(x_in, edges)
         ea = torch.cat([d1, d0], dim=1)
         h1, m1 = blk.gcl_0(h_in, edges, ea, nmf, emf)
+        # GCL internals through the reference's own sub-calls (egnn.py:38-68): gated + masked messages, aggregate
+        msg1, _ = blk.gcl_0.edge_model(h_in[edges[0]], h_in[edges[1]], ea, emf)
+        _, cat1 = blk.gcl_0.node_model(h_in, edges, msg1)
         h_out, x_out = blk(h_in, x_in, edges, nmf, emf, d0)
-    # m1 only for real edges of sample 0's node 0 (small pin on the edge MLP itself)
+    # m1 / msg1 only for the edges of sample 0's node 0 (small pin on the edge MLP itself); agg for every node
     save("block3_b2n20.npz", node_mask=nm, h_in=h_in, x_in=x_in, x0=x0, h_after_gcl0=h1,
-         m_gcl0_node0=m1[:N], h_out=h_out, x_out=x_out, weight_seed=1234)
+         m_gcl0_node0=m1[:N], msg_gcl0_node0=msg1[:N], agg_gcl0=cat1[:, 420:], h_out=h_out, x_out=x_out, block=3,
+         weight_seed=1234, weight_recipe=np.array("v2"))
 
     # 5. full sampler trajectory, config C1 shape (a1-a6): T=20, B=4, N=19
     gm = build_edm(egnn, ed, 20, sd)
@@ -173,17 +177,18 @@ def main():
     with NoiseTape() as tape, torch.no_grad():
         x, h = gm(nm, em, ctx, 0)
     save("sampler_T20_b4n19.npz", node_mask=nm, context=ctx, noise=tape.flat(), z_trace=torch.stack(trace),
-         x=x, h=h, T=20, resample_steps=0, weight_seed=1234)
+         x=x, h=h, T=20, resample_steps=0, weight_seed=1234, weight_recipe=np.array("v2"))
 
-    # 5b. resampling variant (T=8, resample_steps=1)
-    gm = build_edm(egnn, ed, 8, sd)
+    # 5b. resampling variant (T=8, resample_steps=1) - "v2d" weights: see ml_conformer_generator_amd/weights.py
+    sd_d = W.synth_edm_state_dict(1234, recipe="v2d")
+    gm = build_edm(egnn, ed, 8, sd_d)
     torch.manual_seed(32)
     nm, em, ctx = mu.prepare_edm_input(2, dummy_ctx, norms, 15, 17, torch.device("cpu"))
     trace = record_steps(gm)
     with NoiseTape() as tape, torch.no_grad():
         x, h = gm(nm, em, ctx, 1)
     save("sampler_T8_rs1.npz", node_mask=nm, context=ctx, noise=tape.flat(), z_trace=torch.stack(trace),
-         x=x, h=h, T=8, resample_steps=1, weight_seed=1234)
+         x=x, h=h, T=8, resample_steps=1, weight_seed=1234, weight_recipe=np.array("v2d"))
 
     # 6. inpaint + merge_fragments (a14) with a synthetic 8-atom fragment (frag_yibfeu heavy atoms)
     fxyz, fz = parse_molblock_heavy_atoms(open("/root/reference/assets/demo_files/frag_yibfeu.mol").read())
@@ -193,7 +198,7 @@ def main():
     for i, zz in enumerate(fz):
         foh[i, cls[zz]] = 1
     B, N = 3, 19
-    gm = build_edm(egnn, ed, 5, sd)
+    gm = build_edm(egnn, ed, 5, sd_d)
     torch.manual_seed(41)
     nm, em, ctx = mu.prepare_edm_input(B, dummy_ctx, norms, 15, N, torch.device("cpu"))
     n_f = fxyz.size(0)
@@ -206,7 +211,7 @@ def main():
     with NoiseTape() as tape, torch.no_grad():
         x, h = gm.inpaint(nm, em, ctx, z_known, fixed, 1, 3)
     save("inpaint_T5.npz", node_mask=nm, context=ctx, z_known=z_known, fixed_mask=fixed, noise=tape.flat(),
-         z_trace=torch.stack(trace), x=x, h=h, T=5, resample_steps=1, blend_power=3, weight_seed=1234)
+         z_trace=torch.stack(trace), x=x, h=h, T=5, resample_steps=1, blend_power=3, weight_seed=1234, weight_recipe=np.array("v2d"))
 
     gm = build_edm(egnn, ed, 10, sd)
     torch.manual_seed(42)
@@ -216,10 +221,10 @@ def main():
     zk[:, :n_f, 3:] = foh.float()
     trace = record_steps(gm)
     with NoiseTape() as tape, torch.no_grad():
-        x, h = gm.merge_fragments(nm, em, fixed, ctx, zk, diffusion_level=4, resample_steps=1, blend_power=3)
-    save("merge_T10_L4.npz", node_mask=nm, context=ctx, z_known=zk, fixed_mask=fixed, noise=tape.flat(),
-         z_trace=torch.stack(trace), x=x, h=h, T=10, diffusion_level=4, resample_steps=1, blend_power=3,
-         weight_seed=1234)
+        x, h = gm.merge_fragments(nm, em, fixed, ctx, zk, diffusion_level=10, resample_steps=1, blend_power=3)
+    save("merge_T10_L10.npz", node_mask=nm, context=ctx, z_known=zk, fixed_mask=fixed, noise=tape.flat(),
+         z_trace=torch.stack(trace), x=x, h=h, T=10, diffusion_level=10, resample_steps=1, blend_power=3,
+         weight_seed=1234, weight_recipe=np.array("v2"))
     # the level > T failure mode (quirk H5)
     try:
         gm.merge_fragments(nm, em, fixed, ctx, zk, diffusion_level=50)
