@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-phi-calls", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time one denoiser call at B/8 with torch.set_num_threads(os.cpu_count()) (BASELINE.md section 3's "
+                         "rule; ~80 s on the 256-core GPU box, where it is 229x slower than 16 threads)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32x6", "f32x9"],
                     help="bf16 = opt-in reduced-precision MFMA operands (configs[4]); the default bench line is fp32")
     ap.add_argument("--no-config2", action="store_true",
@@ -140,9 +143,10 @@ def cpu_baseline(args, sd, gsd):
 
     Threads: BASELINE.md section 3 says `torch.set_num_threads(os.cpu_count())`.  On the GPU box's 256-core host
     that rule makes the aten kernels ~20x SLOWER than 16 threads (8: 0.68 s, 16: 0.40 s, 32: 0.70 s, 128: 2.7 s per
-    call at B=16): the headline baseline therefore uses the thread count that is best for the CPU (--cpu-threads,
-    default 16), and the os.cpu_count() rule is measured once beside it on a B=8 slice (`all_cores`), so both
-    numbers are on record."""
+    call at B=16; one call at B=8: 0.36 s with 16 threads, 81.9 s with 256 - profiles/round2_bench_c2.json): the
+    headline baseline therefore uses the thread count that is best for the CPU (--cpu-threads, default 16);
+    --cpu-all-cores measures the os.cpu_count() rule beside it on a B/8 slice (`all_cores`), so both numbers are on
+    record."""
     from ml_conformer_generator_amd.synthetic import synth_gcn_inputs
     from oracle import egnn_oracle as EO
     from oracle import gcn_oracle as GO
@@ -168,7 +172,7 @@ def cpu_baseline(args, sd, gsd):
         gcn_s = time.time() - t0
         # the os.cpu_count() rule, on 1/8 of the batch (bounded: the full batch would take minutes per call)
         all_cores = None
-        if n_all != cores:
+        if n_all != cores and args.cpu_all_cores:
             Bs = max(1, B // 8)
             nms, ems = HO.masks_from_sizes(sizes[:Bs], n)
             t0 = time.time()
@@ -341,7 +345,8 @@ def main():
     from ml_conformer_generator_amd import weights as W
     from ml_conformer_generator_amd.synthetic import DUMMY_CONTEXT
 
-    sd = W.synth_edm_state_dict(1234)
+    # (fragment modes: contractive legacy weights - the mutation-checked default gains overflow under resampling)
+    sd = W.synth_edm_state_dict(1234, weight_gain=0.3) if args.fragment else W.synth_edm_state_dict(1234)
     gsd = W.synth_adj_mat_seer_state_dict(4321)
     gen = make_generator(args, dev, args.dtype, sd, gsd)
     ctx = torch.tensor(DUMMY_CONTEXT)

