@@ -7,13 +7,15 @@
  * lives in DEVICE memory unless the name ends in `_host`.  `stream` is a hipStream_t (0 = default).
  * All functions return 0 on success (MCG_OK) or a non-zero code; mcg_last_error() gives the text.
  * No global mutable state except the opaque handles and the process-wide measurement switches below, which are
- * read from the environment (MCG_GRAPH, MCG_X6_GEMM and MCG_NS_MAX_TILES once, on first use, and then cached for the
+ * read from the environment (MCG_GRAPH, MCG_X6_GEMM, MCG_WG_SUMS and MCG_NS_MAX_TILES once, on first use, and then cached for the
  * life of the process; the others at every plan creation / launch) - none is needed for normal operation:
  *   MCG_GRAPH=0          plain launches instead of the captured HIP graph per denoiser call
  *   MCG_NS_MAX_TILES=n   largest batch (16-row edge tiles) that takes the column-split latency edge kernel (512)
  *   MCG_EDGE_MT=1|2      rows/16 per wave of the exact-fp32 edge kernel for new plans
  *   MCG_SPLIT=n          molecule ranges (HIP streams) per plan, overriding the library's choice
- *   MCG_FUSED_NODE=0     node phase as separate launches instead of the fused node-phase kernel
+ *   MCG_WG_SUMS=0        per-wave partial sums + combine / coordinate-update launches instead of the workgroup-level
+ *                        sums of the exact-fp32 throughput edge kernel (read once, cached)
+ *   MCG_SPLIT_FRAC=f     with MCG_SPLIT=2: share of the edge rows given to the first range
  *   MCG_GEMM_RN=1..3, MCG_GEMM_X6_RN=1..3   wave tile width of the node GEMMs
  *   MCG_X6_GEMM=0        f32x6 / f32x9 modes: node GEMMs on the exact fp32 kernel
  *   MCG_VERBOSE=1        graph capture diagnostics on stderr

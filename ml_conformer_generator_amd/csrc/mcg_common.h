@@ -91,6 +91,15 @@ __device__ __forceinline__ int mcg_xcd_remap(int b, int n) {
 #endif
 }
 
+// x / 100 (the reference's normalisation, egnn.py:435) as three FMAs instead of the ~11-instruction IEEE division
+// sequence: q = x * fl(0.01), one residual correction.  Bit-identical to x / 100.0f for every fp32 x with
+// 1e-30 < |x| < 1e38 (tools/native/div100_check.c walks all 2^32 inputs; tests/test_host_logic.py runs a stride of
+// it) - VALU instructions beside a saturated matrix pipe cost ~10x their nominal issue time, so this matters.
+__device__ __forceinline__ float mcg_div100(float x) {
+    const float q = x * 0.01f;
+    return fmaf(fmaf(-q, 100.0f, x), 0.01f, q);
+}
+
 // sum over the 16 lanes that share (lane >> 4): xor-butterfly inside a 16-lane row
 __device__ __forceinline__ float mcg_row16_sum(float v) {
     v += __shfl_xor(v, 1, 64);

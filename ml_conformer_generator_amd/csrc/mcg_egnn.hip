@@ -18,8 +18,10 @@
 #include "mcg_gemm.h"
 #include "mcg_api_internal.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <utility>
 #include <cstring>
 #include <vector>
 
@@ -81,6 +83,11 @@ struct EdgeArgs {
     const int* wave_poff;   // prefix offsets of (wave, node) partial slots
     int n_rows; int n_mtiles; int n_waves;
     float* P;               // GCL: [n_pslots][HP] partial sums;  equiv: [n_pslots][4]
+    // workgroup-level sums (k_edge_lds<1, ., true>): the 4 waves of a workgroup fold their per-tile sums in LDS and
+    // write ONE row per atom and workgroup, already divided by 100:  U [n_uslots + 1][HP] (GCL) / [..][4] (equiv)
+    const int4* wg_info;    // per workgroup: {first global slot, slots, ws0 of its 4 waves (8 bits each), nseg of its 4 waves
+                            // (8 bits each)} - ONE 16-byte scalar load per workgroup
+    float* U;
 };
 
 template <int MT>
@@ -220,6 +227,149 @@ __device__ __forceinline__ void edge_epilogue(const EdgeArgs& p, int wave, bool 
     }
 }
 
+// Workgroup-level epilogue of the throughput kernel (MT = 1, 4 waves = 64 consecutive edge rows).
+// An atom's n-1 rows straddle the 16-row tiles, so every wave holds sums for 1..16 atoms ("segments") of which the
+// first may continue the previous wave's last atom.  Instead of one partial row per (wave, atom) in global memory
+// (7.3 MB per launch at config 2, re-read by a combine kernel), the waves fold their sums in LDS - fixed wave order,
+// no atomics - and the workgroup writes ONE row per atom it touches, already divided by 100 (egnn.py:435): atoms whose
+// rows lie inside the workgroup are final, an atom straddling two workgroups has two rows that the consumer adds
+// (mcg_gemm16_kernel's two-row gather / the coordinate update).  `sl` = LDS scratch: the staging buffer that the tail
+// k-step does not read (16 rows x 432 floats).
+// slot facts of the workgroup's four waves (one 16-byte scalar load at kernel start; kept as packed SCALARS - as
+// small arrays hipcc promotes them to LDS, 10 KiB per workgroup)
+struct WgSums {
+    int sbase, nslots, ws_pack, ns_pack;
+    __device__ __forceinline__ int ws0(int w) const { return (ws_pack >> (8 * w)) & 0xff; }
+    __device__ __forceinline__ int nseg(int w) const { return (ns_pack >> (8 * w)) & 0xff; }
+};
+
+template <bool EQUIV>
+__device__ __forceinline__ void edge_epilogue_wg(const EdgeArgs& p, const WgSums& W, int lane, int wid,
+                                                 f32x4 (&acc)[1][NT], const RowInfo<1>& R, const float* b2p, const float* wvp,
+                                                 float* sl) {
+    const int g = lane >> 4, c = lane & 15;
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float b2 = b2p[nt * 16 + c];
+        const float wv = wvp[nt * 16 + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float m = mcg_silu(acc[0][nt][r] + b2);      // second Linear + SiLU (egnn.py:26-27)
+            acc[0][nt][r] = m;
+            part[r] = fmaf(wv, m, part[r]);
+        }
+    }
+    int rseg[4];
+    float dot[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        dot[r] = mcg_row16_sum(part[r]);
+        rseg[r] = __shfl(R.seg[0], 4 * g + r, 64);
+    }
+    const int nslots = W.nslots, sbase = W.sbase;
+    const int nseg = W.nseg(wid);
+    if (EQUIV) {
+        // per-wave sums of trans = coord_diff * phi * edge_mask (egnn.py:124-127) -> LDS [wave][seg][4], then one
+        // thread per workgroup slot adds the waves' contributions in wave order
+        float* xq = sl;                               // [4][16][4]
+        float tx[4], ty[4], tz[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int src = 4 * g + r;
+            tx[r] = __shfl(R.ux[0], src, 64) * dot[r];
+            ty[r] = __shfl(R.uy[0], src, 64) * dot[r];
+            tz[r] = __shfl(R.uz[0], src, 64) * dot[r];
+        }
+        for (int s = 0; s < nseg; ++s) {
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (rseg[r] == s) { sx += tx[r]; sy += ty[r]; sz += tz[r]; }
+            sx = mcg_group4_sum(sx); sy = mcg_group4_sum(sy); sz = mcg_group4_sum(sz);
+            if (lane == 0) {
+                float* dst = xq + (wid * 16 + s) * 4;
+                dst[0] = sx; dst[1] = sy; dst[2] = sz;
+            }
+        }
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < nslots) {
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int ls = t - W.ws0(w);
+                if (ls >= 0 && ls < W.nseg(w)) {
+                    const float* q = xq + (w * 16 + ls) * 4;
+                    sx += q[0]; sy += q[1]; sz += q[2];
+                }
+            }
+            float* dst = p.U + (size_t)(sbase + t) * 4;
+            dst[0] = sx; dst[1] = sy; dst[2] = sz; dst[3] = 0.f;         // (/100 is applied with the update, after the two-row sum)
+        }
+        return;
+    }
+    // GCL: gate, then the segmented gate-scaled sum over the tile's rows on the matrix pipe (see edge_epilogue)
+    const int sc = (c >> 2) + 4 * (c & 3);
+    float sel[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sel[r] = rseg[r] == sc ? mcg_sigmoid(dot[r] + p.bv) : 0.f;       // att_mlp (egnn.py:36,48)
+    // every wave parks the rows of its segments in LDS at its own offset (the waves' segment counts add up to <= 16
+    // rows by plan construction): segment s sits in register s/4 of lane group s%4
+    int woff = 0;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) woff += w < wid ? W.nseg(w) : 0;
+    static_assert(NT % 3 == 0, "column tiles are processed in threes");
+#pragma unroll
+    for (int nt0 = 0; nt0 < NT; nt0 += 3) {
+        f32x4 d[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) d[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) d[j] = mcg_mfma(sel[t], acc[0][nt0 + j][t], d[j]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[0][nt0 + j] = d[j];            // D rows replace the consumed accumulators
+    }
+    // (one predicated block of 27 LDS stores per register index: a conditional store inside the MFMA loop above turns
+    //  into 108 exec-mask branches that also fence the matrix pipe)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (g + 4 * r < nseg) {
+            float* row = sl + (woff + g + 4 * r) * HP + c;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) row[nt * 16] = acc[0][nt][r];
+        }
+    }
+    __syncthreads();
+    // write-out: one row per workgroup slot = the contributing waves' rows added in wave order (an atom's rows may run
+    // through several waves), divided by the normalisation factor (egnn.py:435).  Wave w takes slots w, w+4, ..; a
+    // lane moves float4 columns `lane` and `lane + 64` (< 108).  Everything that decides WHAT to add is wave-uniform
+    // (scalar branches): this code runs beside the other workgroup's saturated matrix pipe, where every VALU
+    // instruction costs ~10x its nominal issue time.
+    for (int t = wid; t < nslots; t += 4) {
+        f32x4 v0 = (f32x4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        const bool hi = lane < HP / 4 - 64;
+        int off = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int ls = t - W.ws0(w), ns = W.nseg(w);
+            if (ls >= 0 && ls < ns) {
+                const float* row = sl + (off + ls) * HP + 4 * lane;
+                v0 += *reinterpret_cast<const f32x4*>(row);
+                if (hi) v1 += *reinterpret_cast<const f32x4*>(row + 256);
+            }
+            off += ns;
+        }
+        float* dst = p.U + (size_t)(sbase + t) * HP + 4 * lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v0[k] = mcg_div100(v0[k]); v1[k] = mcg_div100(v1[k]); }
+        *reinterpret_cast<f32x4*>(dst) = v0;
+        if (hi) *reinterpret_cast<f32x4*>(dst + 256) = v1;
+    }
+}
+
 // ---- throughput kernel: 4 waves per workgroup share the packed W2 through LDS -------------------
 // (its predecessor - one independent wave per workgroup with B fragments straight from L2 - reached 40 % of the
 //  fp32 MFMA peak: hipcc keeps only 6-10 loads in flight, less than an L2 latency)
@@ -232,7 +382,7 @@ constexpr int GROUP_FLOATS = 4 * NT * 64;          // 6912 floats = 27 KiB: one 
 constexpr int GROUP_LDS_FLOATS = 28 * 256;         // 7 x 1 KiB pieces per wave x 4 waves = 28 KiB
 constexpr int PD = 6;                              // depth of the B-fragment register ring
 
-template <int MT, bool EQUIV>
+template <int MT, bool EQUIV, bool WGC = false>      // WGC: workgroup-level sums (edge_epilogue_wg), MT = 1 only
 __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p) {
     // two staging buffers + the epilogue's per-column parameters (b2 | wv): ONE array on purpose -
     // a second __shared__ object makes hipcc drain vmcnt(0) before the staged ds_reads
@@ -250,6 +400,14 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
     const int wave = live ? wave_raw : p.n_waves - 1;
     RowInfo<MT> R;
     edge_decode<MT, EQUIV>(p, wave, live, c, R);
+    // slot facts of the workgroup-level epilogue: fetched NOW (wave-uniform scalar loads) - at the end of the kernel
+    // their latency would sit in front of a chain of barriers with nothing to overlap it
+    WgSums W = {0, 0, 0, 0};
+    if constexpr (WGC) {
+        const int4 wi = p.wg_info[wg];
+        W.sbase = __builtin_amdgcn_readfirstlane(wi.x); W.nslots = __builtin_amdgcn_readfirstlane(wi.y);
+        W.ws_pack = __builtin_amdgcn_readfirstlane(wi.z); W.ns_pack = __builtin_amdgcn_readfirstlane(wi.w);
+    }
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -393,7 +551,13 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
             for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mcg_mfma(a4[mt][0], b, acc[mt][nt]);
         }
     }
-    edge_epilogue<MT, EQUIV>(p, wave, live, lane, acc, R, lds + 2 * GROUP_LDS_FLOATS, lds + 2 * GROUP_LDS_FLOATS + HP);
+    if constexpr (WGC) {
+        static_assert(MT == 1 && ((H / 16) & 1) == 0, "the tail k-step reads staging buffer 0: buffer 1 is the scratch");
+        edge_epilogue_wg<EQUIV>(p, W, lane, wid, acc, R, lds + 2 * GROUP_LDS_FLOATS, lds + 2 * GROUP_LDS_FLOATS + HP,
+                                lds + GROUP_LDS_FLOATS);
+    } else {
+        edge_epilogue<MT, EQUIV>(p, wave, live, lane, acc, R, lds + 2 * GROUP_LDS_FLOATS, lds + 2 * GROUP_LDS_FLOATS + HP);
+    }
 }
 
 // (A 12-k-group variant of this kernel - 35 groups, no tail step, 51 KiB of LDS, THREE workgroups per CU - was
@@ -1033,25 +1197,50 @@ __global__ void k_coord_update_t(const float* __restrict__ Px, const int* __rest
     if (any) x[(size_t)v * 4 + comp] += s / NORM;
 }
 
+// Stand-alone consumers of the workgroup-level sums (debug hooks and the operand modes whose GEMM kernels cannot
+// gather): x += (Ux[s.x] + Ux[s.y]) / 100, and agg = U[s.x] + U[s.y].
+__global__ void k_coord_apply2(const float* __restrict__ Ux, const int2* __restrict__ slots2, int M, float* __restrict__ x) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = idx >> 2, comp = idx & 3;
+    if (v >= M || comp == 3) return;
+    const int2 sl = slots2[v];
+    x[(size_t)v * 4 + comp] += (Ux[(size_t)sl.x * 4 + comp] + Ux[(size_t)sl.y * 4 + comp]) / NORM;
+}
+__global__ __launch_bounds__(128) void k_gather_agg2(const float* __restrict__ U, const int2* __restrict__ slots2, float* __restrict__ agg) {
+    const int v = blockIdx.x;
+    const int2 sl = slots2[v];
+    for (int col = threadIdx.x; col < HP; col += 128) agg[(size_t)v * HP + col] = U[(size_t)sl.x * HP + col] + U[(size_t)sl.y * HP + col];
+}
+
 // ------------------------------------------------------------------------------ output head
 // h_final = embedding_out(h) (first 8 of 12 channels kept), vel = (x - x0) with the masked
 // mean removed; padded slots of out[B,N,11] are zero  (egnn.py:398-399, :499-513).
+// `ux` / `slots2` (optional): the last block's coordinate update, still pending as workgroup-level sums
+// (x_final = x + (ux[s.x] + ux[s.y]) / 100, egnn.py:128-148).
 __global__ __launch_bounds__(512) void k_output(const float* __restrict__ h, const float* __restrict__ x,
                                                  const float* __restrict__ x0, const int* __restrict__ n_nodes,
                                                  const int* __restrict__ node_off, int N,
                                                  const float* __restrict__ out_w,  // [12][HP]
-                                                 const float* __restrict__ out_b, float* __restrict__ out) {
+                                                 const float* __restrict__ out_b, float* __restrict__ out,
+                                                 const float* __restrict__ ux, const int2* __restrict__ slots2) {
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int n = n_nodes[b];
     const int v0 = node_off[b];
+    // velocity of atom i, component k (with the pending coordinate update folded in)
+    auto vel = [&](int i) {
+        const size_t v = (size_t)(v0 + i);
+        f32x4 xv = *reinterpret_cast<const f32x4*>(x + v * 4);
+        if (ux) {
+            const int2 sl = slots2[v];
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ux + (size_t)sl.x * 4), b = *reinterpret_cast<const f32x4*>(ux + (size_t)sl.y * 4);
+            xv[0] += (a[0] + b[0]) / NORM; xv[1] += (a[1] + b[1]) / NORM; xv[2] += (a[2] + b[2]) / NORM;
+        }
+        return xv - *reinterpret_cast<const f32x4*>(x0 + v * 4);
+    };
     // masked mean of the velocity (every wave computes it: n <= N lanes' worth of work)
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (int i = lane; i < n; i += 64) {
-        sx += x[(size_t)(v0 + i) * 4 + 0] - x0[(size_t)(v0 + i) * 4 + 0];
-        sy += x[(size_t)(v0 + i) * 4 + 1] - x0[(size_t)(v0 + i) * 4 + 1];
-        sz += x[(size_t)(v0 + i) * 4 + 2] - x0[(size_t)(v0 + i) * 4 + 2];
-    }
+    for (int i = lane; i < n; i += 64) { const f32x4 d = vel(i); sx += d[0]; sy += d[1]; sz += d[2]; }
     for (int o = 32; o > 0; o >>= 1) {
         sx += __shfl_xor(sx, o, 64); sy += __shfl_xor(sy, o, 64); sz += __shfl_xor(sz, o, 64);
     }
@@ -1080,9 +1269,10 @@ __global__ __launch_bounds__(512) void k_output(const float* __restrict__ h, con
             accv[k] = s + out_b[k];
         }
         if (lane == 0) {
-            o[0] = (x[(size_t)(v0 + i) * 4 + 0] - x0[(size_t)(v0 + i) * 4 + 0]) - mx;
-            o[1] = (x[(size_t)(v0 + i) * 4 + 1] - x0[(size_t)(v0 + i) * 4 + 1]) - my;
-            o[2] = (x[(size_t)(v0 + i) * 4 + 2] - x0[(size_t)(v0 + i) * 4 + 2]) - mz;
+            const f32x4 d = vel(i);
+            o[0] = d[0] - mx;
+            o[1] = d[1] - my;
+            o[2] = d[2] - mz;
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[3 + k] = accv[k];
         }
@@ -1156,6 +1346,13 @@ struct mcg_plan {
         *wave_poff = nullptr, *node_mol = nullptr, *node_slots = nullptr;   // node_slots: [M][8] or null
     float *x = nullptr, *x0 = nullptr, *h = nullptr, *h2 = nullptr, *pab = nullptr, *agg = nullptr, *t1 = nullptr,
           *P = nullptr, *Px = nullptr;
+    // workgroup-level sums of the throughput edge kernel (MT = 1; see edge_epilogue_wg): one row per (workgroup, atom)
+    bool wgc = false;                       // tables below are valid and every workgroup touches <= 16 atoms
+    int n_uslots = 0;                       // rows of U / Ux (+ one zero row at index n_uslots)
+    int4* wg_info = nullptr;
+    int2* node_slots2 = nullptr;            // per atom: its one or two rows of U (second = the zero row when unused)
+    float *U = nullptr, *Ux = nullptr;
+    bool x_pending = false;                 // host-side: Ux holds a coordinate update that has not been applied to x yet
     std::vector<void*> allocs;
     // optional split into independent molecule ranges that run on separate HIP streams
     // (the latency-bound node GEMMs of one range overlap the edge kernels of the other)
@@ -1317,13 +1514,35 @@ void launch_edge(bool equiv, const EdgeArgs& a, int n_waves, hipStream_t s) {
     else hipLaunchKernelGGL((k_edge_lds<MT, false>), dim3(wgs), dim3(256), 0, s, a);
 }
 
-int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipStream_t s, bool bf16 = false, int x6 = 0) {
+// small batches take the column-split latency variant of the edge kernel (one workgroup per 16-row tile)
+static bool edge_latency_kernel(const mcg_plan* pl) {
+    static int ns_max = -1;
+    if (ns_max < 0) { const char* e = getenv("MCG_NS_MAX_TILES"); ns_max = e ? atoi(e) : 512; }
+    return pl->MT == 1 && (pl->latency_mode == 1 || (pl->latency_mode < 0 && pl->n_mtiles <= ns_max));
+}
+// exact-fp32 throughput kernel with workgroup-level sums (writes pl->U / pl->Ux instead of per-wave partials)
+static bool edge_wgc(const mcg_egnn* m, const mcg_plan* pl) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MCG_WG_SUMS"); on = (e && atoi(e) == 0) ? 0 : 1; }
+    return on && pl->wgc && pl->MT == 1 && !m->bf16 && !m->x6 && !edge_latency_kernel(pl);
+}
+
+int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipStream_t s, bool bf16 = false, int x6 = 0,
+             bool wgc = false) {
     if (pl->n_waves == 0) return MCG_OK;
     EdgeArgs a;
     a.pab = pl->pab; a.x = pl->x; a.x0 = pl->x0; a.wd = L.wd; a.wd0 = L.wd0; a.Bp = L.w2_Bp; a.b2 = L.b2;
     a.wv = L.wv; a.bv = L.bv; a.n_nodes = pl->n_nodes; a.node_off = pl->node_off; a.row_off = pl->row_off;
     a.B = pl->B; a.tile_mol = pl->tile_mol; a.row_ij = pl->row_ij; a.wave_poff = pl->wave_poff;
     a.n_rows = pl->n_rows; a.n_mtiles = pl->n_mtiles; a.n_waves = pl->n_waves; a.P = P;
+    a.wg_info = pl->wg_info; a.U = equiv ? pl->Ux : pl->U;
+    if (wgc) {
+        const int wgs = (pl->n_waves + 3) / 4;
+        if (equiv) hipLaunchKernelGGL((k_edge_lds<1, true, true>), dim3(wgs), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_edge_lds<1, false, true>), dim3(wgs), dim3(256), 0, s, a);
+        MCG_HIP(hipGetLastError());
+        return MCG_OK;
+    }
     if (x6 && pl->MT == 4) {       // (plans with 16/32-row tiles - molecules below 6 atoms - run the exact fp32 kernels)
         a.Bp = reinterpret_cast<const float*>(L.w2_Bp16x3);
         if (x6 == 2) {          // all nine partial products
@@ -1357,9 +1576,7 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
     // small batches: column-split latency variant (one workgroup per 16-row tile).  Measured per edge launch
     // (tools/bench_small.py): <= 256 tiles 24 us, <= 512 tiles 36 us vs 53 us for the throughput kernel's
     // single 16-row chain; beyond 512 tiles the 4x W2 staging traffic makes it slower (59 us at 527 tiles).
-    static int ns_max = -1;
-    if (ns_max < 0) { const char* e = getenv("MCG_NS_MAX_TILES"); ns_max = e ? atoi(e) : 512; }
-    if (pl->MT == 1 && (pl->latency_mode == 1 || (pl->latency_mode < 0 && pl->n_mtiles <= ns_max))) {
+    if (edge_latency_kernel(pl)) {
         if (equiv) hipLaunchKernelGGL((k_edge_ns<true>), dim3(pl->n_mtiles), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_edge_ns<false>), dim3(pl->n_mtiles), dim3(256), 0, s, a);
         MCG_HIP(hipGetLastError());
@@ -1373,12 +1590,24 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
     return MCG_OK;
 }
 
+// `side` (optional): plan whose pending coordinate update rides along as the launch's side job (fp32 kernels only).
+// `rows16` > 0: the 16-row wave-tile kernel with that many column tiles per wave; `a2_rows`: two-row gather of A2.
 int gemm(const float* A1, int lda1, int K1, const float* A2, int lda2, int K2, const float* Bp, const float* bias,
          const float* resid, int ldr, float* C, int ldc, int M, int n_tiles, int n_store, int act, hipStream_t s,
-         const uint16_t* Bp16 = nullptr, const uint16_t* Bp16x3 = nullptr) {
-    McgGemmArgs g;
+         const uint16_t* Bp16 = nullptr, const uint16_t* Bp16x3 = nullptr, mcg_plan* side = nullptr, int rows16 = 0,
+         const int2* a2_rows = nullptr) {
+    McgGemmArgs g{};
     g.A1 = A1; g.lda1 = lda1; g.K1 = K1; g.A2 = A2; g.lda2 = lda2; g.K2 = K2; g.Bp = Bp; g.bias = bias;
     g.resid = resid; g.ldr = ldr; g.C = C; g.ldc = ldc; g.M = M; g.n_tiles = n_tiles; g.n_store = n_store; g.act = act;
+    if (side && side->x_pending && !Bp16 && !Bp16x3) {
+        g.side_u = side->Ux; g.side_slots = side->node_slots2; g.side_x = side->x; g.side_M = side->M;
+        side->x_pending = false;
+    }
+    if (rows16 > 0 && !Bp16 && !Bp16x3) {
+        g.a2_rows = a2_rows;
+        MCG_HIP(mcg_gemm16_launch(g, rows16, s));
+        return MCG_OK;
+    }
     if (Bp16x3) {            // f32x6: three-part operands on the bf16 pipe, fp32-accurate
         g.Bp = reinterpret_cast<const float*>(Bp16x3);
         MCG_HIP(mcg_gemm_x6_launch(g, s));
@@ -1389,25 +1618,51 @@ int gemm(const float* A1, int lda1, int K1, const float* A2, int lda2, int K2, c
     return MCG_OK;
 }
 
+// pending coordinate update (workgroup-level sums in pl->Ux) applied by a stand-alone launch
+int apply_pending_x(mcg_plan* pl, hipStream_t s) {
+    if (!pl->x_pending) return MCG_OK;
+    hipLaunchKernelGGL(k_coord_apply2, dim3((pl->M * 4 + 255) / 256), dim3(256), 0, s, pl->Ux, pl->node_slots2, pl->M, pl->x);
+    MCG_HIP(hipGetLastError());
+    pl->x_pending = false;
+    return MCG_OK;
+}
+
 // One GCL layer on the plan's compact state: h (in pl->h) -> pl->h  (egnn.py:70-85)
-int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s) {
+int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s, bool keep_agg = false) {
     const EdgeLayer& E = m->gcl_edge[layer];
     const NodeLayer& Nl = m->gcl_node[layer];
     const int M = pl->M;
     const bool lp = m->bf16;
     const bool x6g = m->x6 != 0 && g_x6_gemm();
+    const bool wgc = edge_wgc(m, pl);
+    const bool f32 = !lp && !x6g;
+    // (a pending coordinate update of the previous block rides along with this launch; the other operand modes'
+    //  GEMM kernels have no side job: apply it first)
+    if (!f32) { if (int e = apply_pending_x(pl, s)) return e; }
     if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
-                     MCG_ACT_NONE, s, lp ? E.pab_Bp16 : nullptr, x6g ? E.pab_Bp16x3 : nullptr)) return e;
-    if (int e = run_edge(pl, E, false, pl->P, s, lp, m->x6)) return e;
-    // (reading the partials directly in the node GEMM's A-loader was tried: the 4-way gather costs the
-    //  GEMM as much as the ~6 us combine launch it saves at config 2 and more at config 3)
-    hipLaunchKernelGGL(k_combine_agg_t, dim3(M), dim3(128), 0, s, pl->P, pl->node_slots, pl->agg);
-    MCG_HIP(hipGetLastError());
-    // node_mlp: h + W4 silu(W3 [h | agg] + b3) + b4   (egnn.py:30-34,66-67)
-    if (int e = gemm(pl->h, HP, H, pl->agg, HP, H, Nl.w3_Bp, Nl.b3, nullptr, 0, pl->t1, HP, M, NT, HP, MCG_ACT_SILU, s,
-                     lp ? Nl.w3_Bp16 : nullptr, x6g ? Nl.w3_Bp16x3 : nullptr)) return e;
+                     MCG_ACT_NONE, s, lp ? E.pab_Bp16 : nullptr, x6g ? E.pab_Bp16x3 : nullptr, pl)) return e;
+    if (int e = apply_pending_x(pl, s)) return e;              // (only if the GEMM above could not carry it)
+    if (int e = run_edge(pl, E, false, pl->P, s, lp, m->x6, wgc)) return e;
+    const int2* gather = nullptr;
+    if (wgc && f32 && !keep_agg) {
+        gather = pl->node_slots2;                               // the node GEMM adds an atom's two rows of U itself
+    } else if (wgc) {
+        hipLaunchKernelGGL(k_gather_agg2, dim3(M), dim3(128), 0, s, pl->U, pl->node_slots2, pl->agg);
+        MCG_HIP(hipGetLastError());
+    } else {
+        // (reading the per-wave partials directly in the node GEMM's A-loader was tried: the 4-way gather costs the
+        //  GEMM as much as the ~6 us combine launch it saves at config 2 and more at config 3)
+        hipLaunchKernelGGL(k_combine_agg_t, dim3(M), dim3(128), 0, s, pl->P, pl->node_slots, pl->agg);
+        MCG_HIP(hipGetLastError());
+    }
+    // node_mlp: h + W4 silu(W3 [h | agg] + b3) + b4   (egnn.py:30-34,66-67).  16-row wave tiles of 3 column tiles
+    // balance these two GEMMs on 1024 SIMDs for M up to ~2.3k rows (972 waves at config 2); beyond that the
+    // 32-row kernel's cost model takes over.
+    const int r16 = (f32 && M <= 2304) ? 3 : 0;
+    if (int e = gemm(pl->h, HP, H, gather ? pl->U : pl->agg, HP, H, Nl.w3_Bp, Nl.b3, nullptr, 0, pl->t1, HP, M, NT, HP, MCG_ACT_SILU, s,
+                     lp ? Nl.w3_Bp16 : nullptr, x6g ? Nl.w3_Bp16x3 : nullptr, nullptr, gather ? 3 : r16, gather)) return e;
     if (int e = gemm(pl->t1, HP, H, nullptr, 0, 0, Nl.w4_Bp, Nl.b4, pl->h, HP, pl->h2, HP, M, NT, HP, MCG_ACT_NONE, s,
-                     lp ? Nl.w4_Bp16 : nullptr, x6g ? Nl.w4_Bp16x3 : nullptr)) return e;
+                     lp ? Nl.w4_Bp16 : nullptr, x6g ? Nl.w4_Bp16x3 : nullptr, nullptr, r16)) return e;
     std::swap(pl->h, pl->h2);
     return MCG_OK;
 }
@@ -1415,9 +1670,14 @@ int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s) {
 int run_equiv(const mcg_egnn* m, mcg_plan* pl, int block, hipStream_t s) {
     const EdgeLayer& E = m->equiv[block];
     const int M = pl->M;
+    const bool wgc = edge_wgc(m, pl);
     if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
                      MCG_ACT_NONE, s, m->bf16 ? E.pab_Bp16 : nullptr, (m->x6 != 0 && g_x6_gemm()) ? E.pab_Bp16x3 : nullptr)) return e;
-    if (int e = run_edge(pl, E, true, pl->Px, s, m->bf16, m->x6)) return e;
+    if (int e = run_edge(pl, E, true, pl->Px, s, m->bf16, m->x6, wgc)) return e;
+    if (wgc) {
+        pl->x_pending = true;          // applied by the next launch that can carry it (next block's first GEMM / k_output)
+        return MCG_OK;
+    }
     const int threads = M * 4;
     hipLaunchKernelGGL(k_coord_update_t, dim3((threads + 255) / 256), dim3(256), 0, s, pl->Px, pl->node_slots, M, pl->x);
     MCG_HIP(hipGetLastError());
@@ -1612,6 +1872,68 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
             }
         }
     }
+    // workgroup-level tables (MT = 1): workgroup w = units 4w .. 4w+3 = rows [64w, 64w + 64)
+    std::vector<int> wave_ws(p->n_waves + 1, 0), wg_sbase, wg_info;
+    std::vector<int> node_slots2((size_t)(p->M > 0 ? p->M : 1) * 2, 0);
+    bool wgc_ok = best == 1 && p->n_waves > 0;
+    if (wgc_ok) {
+        const int n_wg = (p->n_waves + 3) / 4;
+        wg_sbase.assign(n_wg + 1, 0);
+        wg_info.assign((size_t)n_wg * 4, 0);
+        std::vector<int> first_node(p->n_waves, -1), last_node(p->n_waves, -1);
+        for (int b = 0; b < B; ++b) {
+            const int n = nn[b];
+            for (int i = 0; i < n && n > 1; ++i) {
+                const int v = node_off[b] + i;
+                const int first = row_off[b] + i * (n - 1), last = first + n - 2;
+                for (int u = first / 16; u <= last / 16; ++u) {
+                    if (first_node[u] < 0) first_node[u] = v;
+                    last_node[u] = v;
+                }
+            }
+        }
+        for (int w = 0; w < n_wg; ++w) {
+            int slots = 0, rows = 0;                // rows: LDS rows the waves park their segment sums in (<= 16 fit)
+            for (int u = 4 * w; u < std::min(4 * w + 4, p->n_waves); ++u) {
+                const int nseg = wave_poff[u + 1] - wave_poff[u];
+                rows += nseg;
+                const bool cont = u > 4 * w && nseg > 0 && first_node[u] == last_node[u - 1];
+                const int ws0 = cont ? slots - 1 : slots;
+                wave_ws[u] = ws0 | ((cont ? 1 : 0) << 8);
+                slots = ws0 + nseg;
+            }
+            if (rows > 16) wgc_ok = false;
+            int ws_pack = 0, ns_pack = 0;
+            for (int u = 4 * w; u < std::min(4 * w + 4, p->n_waves); ++u) {
+                ws_pack |= (wave_ws[u] & 0xff) << (8 * (u - 4 * w));
+                ns_pack |= ((wave_poff[u + 1] - wave_poff[u]) & 0xff) << (8 * (u - 4 * w));
+            }
+            wg_info[4 * (size_t)w] = wg_sbase[w]; wg_info[4 * (size_t)w + 1] = slots;
+            wg_info[4 * (size_t)w + 2] = ws_pack; wg_info[4 * (size_t)w + 3] = ns_pack;
+            wg_sbase[w + 1] = wg_sbase[w] + slots;
+        }
+        p->n_uslots = wg_sbase[n_wg];
+        const int zero = p->n_uslots;
+        for (int v = 0; v < p->M; ++v) node_slots2[2 * v] = node_slots2[2 * v + 1] = zero;
+        for (int b = 0; b < B && wgc_ok; ++b) {
+            const int n = nn[b];
+            for (int i = 0; i < n && n > 1; ++i) {
+                const int v = node_off[b] + i;
+                const int first = row_off[b] + i * (n - 1), last = first + n - 2;
+                const int w_lo = first / 64, w_hi = last / 64;
+                if (w_hi - w_lo > 1) { wgc_ok = false; break; }
+                // slot of atom v inside workgroup w = slot of the unit holding its first row there + its segment there
+                auto slot_in = [&](int w) {
+                    const int r = std::max(first, 64 * w);
+                    const int u = r / 16;
+                    return wg_sbase[w] + (wave_ws[u] & 0xff) + (ij[2 * (size_t)r + 1] >> 24);
+                };
+                node_slots2[2 * v] = slot_in(w_lo);
+                if (w_hi > w_lo) node_slots2[2 * v + 1] = slot_in(w_hi);
+            }
+        }
+    }
+    p->wgc = wgc_ok;
     if (!segs_ok) {
         mcg_set_error("mcg_plan_create: edge_mt = %d puts more than 16 atoms' rows into one %d-row unit (molecules this "
                       "small need edge_mt = 1)", best, R);
@@ -1635,6 +1957,14 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
     e |= upload_i(nn, &p->n_nodes); e |= upload_i(node_off, &p->node_off); e |= upload_i(row_off, &p->row_off);
     e |= upload_i(tile_mol, &p->tile_mol); e |= upload_i(wave_poff, &p->wave_poff);
     e |= upload_i(node_mol, &p->node_mol);
+    if (p->wgc) {
+        int* d = nullptr;
+        int* wi = nullptr;
+        e |= upload_i(wg_info, &wi); e |= upload_i(node_slots2, &d);
+        p->wg_info = reinterpret_cast<int4*>(wi);
+        p->node_slots2 = reinterpret_cast<int2*>(d);
+        p->allocs.insert(p->allocs.end(), {(void*)wi, (void*)d});
+    }
     if (e) { mcg_plan_destroy(p); return MCG_ERR_HIP; }
     p->allocs.insert(p->allocs.end(), {(void*)p->n_nodes, (void*)p->node_off, (void*)p->row_off, (void*)p->tile_mol,
                                        (void*)p->wave_poff, (void*)p->node_mol});
@@ -1642,7 +1972,8 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
     struct { float** ptr; size_t n; } bufs[] = {
         // (+64 floats: the bf16 kernels read activation rows up to k = 447, i.e. 16 floats past the last row)
         {&p->x, M1 * 4}, {&p->x0, M1 * 4}, {&p->h, M1 * HP + 64}, {&p->h2, M1 * HP + 64}, {&p->pab, M1 * 2 * HP + 64},
-        {&p->agg, M1 * HP + 64}, {&p->t1, M1 * HP + 64}, {&p->P, (size_t)(p->n_pslots + 1) * HP}, {&p->Px, (size_t)(p->n_pslots + 1) * 4}};
+        {&p->agg, M1 * HP + 64}, {&p->t1, M1 * HP + 64}, {&p->P, (size_t)(p->n_pslots + 1) * HP}, {&p->Px, (size_t)(p->n_pslots + 1) * 4},
+        {&p->U, (size_t)(p->n_uslots + 1) * HP + 64}, {&p->Ux, (size_t)(p->n_uslots + 1) * 4}};
     for (auto& b : bufs) {
         if (hipMalloc((void**)b.ptr, b.n * sizeof(float)) != hipSuccess || hipMemset(*b.ptr, 0, b.n * sizeof(float)) != hipSuccess) {
             mcg_set_error("mcg_plan_create: out of device memory (%zu floats)", b.n);
@@ -1707,7 +2038,8 @@ static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, i
     for (int k = 0; k < parts; ++k) {
         int b1 = B;
         if (k + 1 < parts) {
-            const long target = cum[B] * (k + 1) / parts;
+            long target = cum[B] * (k + 1) / parts;
+            if (parts == 2) if (const char* e = getenv("MCG_SPLIT_FRAC")) target = (long)(cum[B] * atof(e));   // measurement only
             b1 = b0 + 1;
             while (b1 < B && cum[b1] < target) ++b1;
         }
@@ -1757,6 +2089,7 @@ static int dynamics_launch(const mcg_egnn* m, mcg_plan* pl, const float* t, cons
         }
         return MCG_OK;
     }
+    pl->x_pending = false;
     if (pl->M > 0) {
         hipLaunchKernelGGL(k_prep_embed, dim3(pl->M), dim3(128), 0, s, xh, t, context, pl->node_mol, pl->node_off, pl->N,
                            m->emb_wT, m->emb_b, pl->h, pl->x, pl->x0);
@@ -1764,9 +2097,12 @@ static int dynamics_launch(const mcg_egnn* m, mcg_plan* pl, const float* t, cons
         for (int b = 0; b < m->n_blocks; ++b)
             if (int e = run_block(m, pl, b, s)) return e;
     }
+    // (the last block's coordinate update is folded into the output head)
     hipLaunchKernelGGL(k_output, dim3(pl->B), dim3(512), 0, s, pl->h, pl->x, pl->x0, pl->n_nodes, pl->node_off, pl->N,
-                       m->out_w, m->out_b, out);
+                       m->out_w, m->out_b, out, pl->x_pending ? pl->Ux : (const float*)nullptr,
+                       pl->x_pending ? pl->node_slots2 : (const int2*)nullptr);
     MCG_HIP(hipGetLastError());
+    pl->x_pending = false;
     return MCG_OK;
 }
 
@@ -1841,7 +2177,7 @@ int mcg_bench_edge(const mcg_egnn* m, mcg_plan* pl, int layer, int equiv, int it
     if (!m || !pl || iters < 1 || layer < 0 || layer >= (equiv ? m->n_blocks : 2 * m->n_blocks)) return MCG_ERR_ARG;
     for (int i = 0; i < iters; ++i)
         if (int e = run_edge(pl, equiv ? m->equiv[layer] : m->gcl_edge[layer], equiv != 0, equiv ? pl->Px : pl->P,
-                             (hipStream_t)stream, m->bf16, m->x6)) return e;
+                             (hipStream_t)stream, m->bf16, m->x6, edge_wgc(m, pl))) return e;
     return MCG_OK;
 }
 
@@ -1873,7 +2209,8 @@ int mcg_egnn_gcl_debug(const mcg_egnn* m, mcg_plan* pl, int layer, const float* 
     MCG_HIP(hipMemcpy2DAsync(pl->h, HP * sizeof(float), h_in, H * sizeof(float), H * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));
     MCG_HIP(hipMemcpy2DAsync(pl->x, 4 * sizeof(float), x_in, 3 * sizeof(float), 3 * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));
     MCG_HIP(hipMemcpy2DAsync(pl->x0, 4 * sizeof(float), x0, 3 * sizeof(float), 3 * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));
-    return run_gcl(m, pl, layer, s);
+    pl->x_pending = false;
+    return run_gcl(m, pl, layer, s, /*keep_agg=*/true);      // (agg materialised for mcg_plan_peek)
 }
 
 // Kernel-level pin: run ONE EquivariantBlock on compact state (egnn.py:188-222).
@@ -1888,7 +2225,9 @@ int mcg_egnn_block_debug(const mcg_egnn* m, mcg_plan* pl, int block, float* h_io
     MCG_HIP(hipMemcpy2DAsync(pl->h, HP * sizeof(float), h_io, H * sizeof(float), H * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));
     MCG_HIP(hipMemcpy2DAsync(pl->x, 4 * sizeof(float), x_io, 3 * sizeof(float), 3 * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));
     MCG_HIP(hipMemcpy2DAsync(pl->x0, 4 * sizeof(float), x0, 3 * sizeof(float), 3 * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));
+    pl->x_pending = false;
     if (int e = run_block(m, pl, block, s)) return e;
+    if (int e = apply_pending_x(pl, s)) return e;
     MCG_HIP(hipMemcpy2DAsync(h_io, H * sizeof(float), pl->h, HP * sizeof(float), H * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));
     MCG_HIP(hipMemcpy2DAsync(x_io, 3 * sizeof(float), pl->x, 4 * sizeof(float), 3 * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));
     return MCG_OK;

@@ -202,7 +202,7 @@ int ensure_ws(mcg_gcn* g, int B) {
 }
 
 int lin(const Lin& L, const float* A, int lda, float* C, int ldc, int M, int n_store, hipStream_t s) {
-    McgGemmArgs a;
+    McgGemmArgs a{};
     a.A1 = A; a.lda1 = lda; a.K1 = L.K; a.A2 = nullptr; a.lda2 = 0; a.K2 = 0; a.Bp = L.Bp; a.bias = L.bias;
     a.resid = nullptr; a.ldr = 0; a.C = C; a.ldc = ldc; a.M = M; a.n_tiles = L.n_tiles; a.n_store = n_store;
     a.act = MCG_ACT_NONE;

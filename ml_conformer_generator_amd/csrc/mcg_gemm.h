@@ -16,6 +16,7 @@
 #include "mcg_common.h"
 
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 enum { MCG_ACT_NONE = 0, MCG_ACT_SILU = 1, MCG_ACT_RELU = 2 };
@@ -37,7 +38,25 @@ struct McgGemmArgs {
     float* C; int ldc;
     int M; int n_tiles; int n_store;        // columns >= n_store are not written
     int act;
+    // --- mcg_gemm16_kernel only (value-initialise the struct: zero = unused) ---
+    const int2* a2_rows;                    // optional: row r of segment 2 is the SUM of rows a2_rows[r].x and .y of A2
+                                            // (the two workgroup-level partial-sum slots of a node, mcg_egnn.hip)
+    // side job run by the blocks beyond the GEMM's own grid (independent data, saves a launch):
+    // x[v][0..2] += (side_u[s.x] + side_u[s.y]) / 100 - the coordinate update of the previous block (egnn.py:128-148)
+    const float* side_u; const int2* side_slots; float* side_x; int side_M;
+    int gemm_blocks;                        // workgroups of the GEMM proper (set by the launcher)
 };
+
+// Side job of the fp32 node GEMM launches (workgroups beyond the GEMM's own grid): the coordinate update of the
+// previous EquivariantBlock, x[v] += (u[s.x] + u[s.y]) / 100 (egnn.py:128-148) - independent data, saves a launch.
+__device__ __forceinline__ void mcg_gemm_side_job(const McgGemmArgs& p, int block) {
+    const int idx = block * 256 + (int)threadIdx.x;
+    const int v = idx >> 2, comp = idx & 3;
+    if (v < p.side_M && comp < 3) {
+        const int2 sl = p.side_slots[v];
+        p.side_x[(size_t)v * 4 + comp] += (p.side_u[(size_t)sl.x * 4 + comp] + p.side_u[(size_t)sl.y * 4 + comp]) / 100.0f;
+    }
+}
 
 // floats occupied by one K segment of a B-pack4
 __host__ __device__ static inline size_t mcg_pack4_floats(int K, int n_tiles) { return (size_t)(K / 4) * n_tiles * 64; }
@@ -428,7 +447,9 @@ __global__ __launch_bounds__(256) void mcg_gemm_kernel(McgGemmArgs p) {
     // ceil(waves / 4) workgroups - a 2-D grid rounds each row block up to whole workgroups and
     // can push a 243-workgroup problem over the 256-CU edge into a second round.
     const int wave_cols = (p.n_tiles + RN - 1) / RN;
-    const int wlin = MCG_GEMM_BLOCK(blockIdx.x, gridDim.x) * 4 + wid;
+    const int nblk = p.gemm_blocks > 0 ? p.gemm_blocks : (int)gridDim.x;        // (+ side-job workgroups behind them)
+    if ((int)blockIdx.x >= nblk) { mcg_gemm_side_job(p, (int)blockIdx.x - nblk); return; }
+    const int wlin = MCG_GEMM_BLOCK(blockIdx.x, nblk) * 4 + wid;
     if (wlin >= ((p.M + 31) / 32) * wave_cols) return;
     const int row0 = (wlin / wave_cols) * 32;
     const int nt0 = (wlin % wave_cols) * RN;
@@ -582,6 +603,154 @@ __global__ __launch_bounds__(256) void mcg_gemm_kernel(McgGemmArgs p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 16-row variant for the node GEMMs (M = 1.7k .. 7k rows): a wave owns ONE 16-row tile x RN column tiles.
+// With 32-row wave tiles the three GEMMs of a GCL layer quantise badly on 1024 SIMDs at M = 1728 (K = 840,
+// N = 432: 756 waves of 840 MFMAs = 11.2 us of serial chain on 74 % of the SIMDs); 16 x 3 tiles give 972 waves
+// of 630 MFMAs (8.4 us), 16 x 6 the same for N = 864.  Same operand packs, ring discipline and transposed
+// accumulators as mcg_gemm_kernel.  GATHER: segment-2 rows are read as the sum of two rows (see a2_rows).
+template <int RN, bool GATHER, int RING = 3>
+__global__ __launch_bounds__(256) void mcg_gemm16_kernel(McgGemmArgs p) {
+    if ((int)blockIdx.x >= p.gemm_blocks) { mcg_gemm_side_job(p, (int)blockIdx.x - p.gemm_blocks); return; }
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int wave_cols = (p.n_tiles + RN - 1) / RN;
+    const int wlin = MCG_GEMM_BLOCK(blockIdx.x, p.gemm_blocks) * 4 + wid;
+    if (wlin >= ((p.M + 15) / 16) * wave_cols) return;
+    const int row0 = (wlin / wave_cols) * 16;
+    const int nt0 = (wlin % wave_cols) * RN;
+    const int orow = row0 + c;
+    const int rA = orow < p.M ? orow : p.M - 1;           // clamp: results of padded rows are dropped
+    bool nvalid[RN];
+    int ncl[RN];
+#pragma unroll
+    for (int n = 0; n < RN; ++n) {
+        nvalid[n] = nt0 + n < p.n_tiles;
+        ncl[n] = nvalid[n] ? n : 0;
+    }
+    f32x4 acc[RN];
+#pragma unroll
+    for (int n = 0; n < RN; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ebias[RN], eres[RN];
+#pragma unroll
+    for (int n = 0; n < RN; ++n) {
+        const int col = (nt0 + ncl[n]) * 16 + 4 * g;
+        ebias[n] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        eres[n] = (p.resid && orow < p.M && col + 3 < p.n_store) ? *reinterpret_cast<const f32x4*>(p.resid + (size_t)orow * p.ldr + col)
+                                                                 : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const float* bseg = p.Bp;
+    // one K segment; TWO: activation rows are the sum of two rows (row indices ra, rb)
+    auto segment = [&](auto two_tag, const float* A, int K, int lda, int ra, int rb) {
+        constexpr bool TWO = decltype(two_tag)::value;
+        const int groups = K / 16;
+        const size_t gstride = (size_t)p.n_tiles * 256;
+        if (groups > 0) {
+            f32x4 Ar[RING], Ar2[RING], Br[RING][RN];
+            const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, 0xffffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bseg), 0, 0xffffffff, 0x00020000);
+            const unsigned oa = (unsigned)(ra * lda + 4 * g) * 4u, oa2 = (unsigned)(rb * lda + 4 * g) * 4u;
+            unsigned obn[RN];
+#pragma unroll
+            for (int n = 0; n < RN; ++n) obn[n] = (unsigned)((nt0 + ncl[n]) * 256 + lane * 4) * 4u;
+            const int gbytes = p.n_tiles * 256 * 4;
+            auto load_group = [&](int slot, int q) {
+                q = q < groups ? q : groups - 1;
+                Ar[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)oa, 64 * q, 0));
+                if (TWO) Ar2[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)oa2, 64 * q, 0));
+#pragma unroll
+                for (int n = 0; n < RN; ++n)
+                    Br[slot][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)obn[n], q * gbytes, 0));
+            };
+            auto compute = [&](int slot) {
+                const f32x4 a = TWO ? Ar[slot] + Ar2[slot] : Ar[slot];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int n = 0; n < RN; ++n) acc[n] = mcg_mfma(Br[slot][n][s], a[s], acc[n]);
+            };
+#pragma unroll
+            for (int i = 0; i < RING; ++i) load_group(i, i);
+            int q = 0;
+#pragma unroll 1
+            for (; q + RING <= groups; q += RING) {
+#pragma unroll
+                for (int i = 0; i < RING; ++i) {
+                    compute(i); __builtin_amdgcn_sched_barrier(0); load_group(i, q + RING + i); __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RING - 1; ++i)
+                if (q + i < groups) compute(i);
+        }
+        const int tail = (K - groups * 16) / 4;
+        const float* bt = bseg + (size_t)groups * gstride + (size_t)nt0 * 64 + lane;
+        for (int st = 0; st < tail; ++st) {
+            const int k = groups * 16 + 4 * st + g;                    // k = 16Q + 4st + g
+            float av = A[(size_t)ra * lda + k];
+            if (TWO) av += A[(size_t)rb * lda + k];
+#pragma unroll
+            for (int n = 0; n < RN; ++n) acc[n] = mcg_mfma(bt[(size_t)st * p.n_tiles * 64 + ncl[n] * 64], av, acc[n]);
+        }
+        bseg += mcg_pack4_floats(K, p.n_tiles);
+    };
+    if (p.K1 > 0) segment(std::false_type{}, p.A1, p.K1, p.lda1, rA, rA);
+    if (p.K2 > 0) {
+        if (GATHER) {
+            const int2 sl = p.a2_rows[rA];
+            segment(std::true_type{}, p.A2, p.K2, p.lda2, sl.x, sl.y);
+        } else {
+            segment(std::false_type{}, p.A2, p.K2, p.lda2, rA, rA);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < RN; ++n) {
+        if (!nvalid[n]) continue;
+        const int col = (nt0 + n) * 16 + 4 * g;
+        if (col >= p.n_store || orow >= p.M) continue;
+        f32x4 v = acc[n] + ebias[n];
+        if (p.act == MCG_ACT_SILU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = mcg_silu(v[r]);
+        } else if (p.act == MCG_ACT_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        v += eres[n];
+        float* dst = p.C + (size_t)orow * p.ldc + col;
+        if (col + 3 < p.n_store) {
+            *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (col + r < p.n_store) dst[r] = v[r];
+        }
+    }
+}
+
+// launcher of the 16-row variant.  rn in {2, 3, 6}; the optional side job adds ceil(side_M * 4 / 256) workgroups.
+static inline hipError_t mcg_gemm16_launch(McgGemmArgs a, int rn, hipStream_t s) {
+    if (a.M <= 0) return hipSuccess;
+    const long waves = (long)((a.M + 15) / 16) * ((a.n_tiles + rn - 1) / rn);
+    a.gemm_blocks = (int)((waves + 3) / 4);
+    const int side = a.side_x ? (a.side_M * 4 + 255) / 256 : 0;
+    const dim3 grid((unsigned)(a.gemm_blocks + side));
+    const bool gather = a.a2_rows != nullptr && a.K2 > 0;
+    if (rn == 6) {
+        if (gather) hipLaunchKernelGGL((mcg_gemm16_kernel<6, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((mcg_gemm16_kernel<6, false>), grid, dim3(256), 0, s, a);
+    } else if (rn == 3) {
+        if (gather) hipLaunchKernelGGL((mcg_gemm16_kernel<3, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((mcg_gemm16_kernel<3, false>), grid, dim3(256), 0, s, a);
+    } else {
+        if (gather) hipLaunchKernelGGL((mcg_gemm16_kernel<2, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((mcg_gemm16_kernel<2, false>), grid, dim3(256), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
 static inline hipError_t mcg_gemm_launch(const McgGemmArgs& a, hipStream_t s, bool bf16 = false) {
     if (a.M <= 0) return hipSuccess;
     const int rowblocks = (a.M + 31) / 32;
@@ -614,6 +783,15 @@ static inline hipError_t mcg_gemm_launch(const McgGemmArgs& a, hipStream_t s, bo
     if (const char* e = getenv("MCG_GEMM_RN")) { const int v = atoi(e); if (v >= 1 && v <= 3) rn = v; }
     const long waves = (long)rowblocks * ((a.n_tiles + rn - 1) / rn);
     dim3 grid((unsigned)((waves + 3) / 4));
+    if (!bf16 && a.side_x) {                 // fp32 kernel only: coordinate-update side job behind the GEMM's workgroups
+        McgGemmArgs b = a;
+        b.gemm_blocks = (int)grid.x;
+        grid.x += (unsigned)((a.side_M * 4 + 255) / 256);
+        if (rn == 3) hipLaunchKernelGGL(mcg_gemm_kernel<3>, grid, dim3(256), 0, s, b);
+        else if (rn == 2) hipLaunchKernelGGL(mcg_gemm_kernel<2>, grid, dim3(256), 0, s, b);
+        else hipLaunchKernelGGL(mcg_gemm_kernel<1>, grid, dim3(256), 0, s, b);
+        return hipGetLastError();
+    }
     if (bf16) {
         if (rn == 3) hipLaunchKernelGGL(mcg_gemm_bf16_kernel<3>, grid, dim3(256), 0, s, a);
         else if (rn == 2) hipLaunchKernelGGL(mcg_gemm_bf16_kernel<2>, grid, dim3(256), 0, s, a);

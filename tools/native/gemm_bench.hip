@@ -72,6 +72,32 @@ int main(int argc, char** argv) {
             printf("M=%d ring=%d %-26s RN=%d  %.1f us  %.1f TFLOP/s\n", M, RINGS, names[which], rn, ms * 1e3 / iters, flops[which] / (ms * 1e-3 / iters) / 1e12);
         }
     }
+    // 16-row wave tiles (mcg_gemm16_kernel): RN = 2 / 3 / 6, and the two-slot gather form of the W3 GEMM
+    {
+        std::vector<int> sl(2 * (size_t)M);
+        for (int v = 0; v < M; ++v) { sl[2 * v] = v; sl[2 * v + 1] = (v * 7 + 3) % M; }
+        int2* slots; hipMalloc(&slots, sl.size() * 4); hipMemcpy(slots, sl.data(), sl.size() * 4, hipMemcpyHostToDevice);
+        for (int which = 0; which < 3; ++which)
+            for (int gather = 0; gather <= (which == 1 ? 1 : 0); ++gather)
+                for (int rn : {2, 3, 6}) {
+                    auto run = [&](int n) {
+                        for (int i = 0; i < n; ++i) {
+                            McgGemmArgs g = args(which, i % SETS);
+                            if (gather) g.a2_rows = slots;
+                            mcg_gemm16_launch(g, rn, s);
+                        }
+                    };
+                    run(SETS);
+                    hipStreamSynchronize(s);
+                    hipEventRecord(e0, s);
+                    run(iters);
+                    hipEventRecord(e1, s);
+                    hipStreamSynchronize(s);
+                    float ms; hipEventElapsedTime(&ms, e0, e1);
+                    printf("M=%d 16-row %-26s RN=%d%s  %.1f us  %.1f TFLOP/s\n", M, names[which], rn, gather ? " gather2" : "", ms * 1e3 / iters,
+                           flops[which] / (ms * 1e-3 / iters) / 1e12);
+                }
+    }
     // duration vs K for the Pab shape (RN = 3): separates the per-launch floor from the per-k cost
     for (int K : {16, 112, 208, 304, 420}) {
         auto run = [&](int n) {
