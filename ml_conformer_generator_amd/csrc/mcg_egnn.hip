@@ -1605,7 +1605,9 @@ int gemm(const float* A1, int lda1, int K1, const float* A2, int lda2, int K2, c
     }
     if (rows16 > 0 && !Bp16 && !Bp16x3) {
         g.a2_rows = a2_rows;
-        MCG_HIP(mcg_gemm16_launch(g, rows16, s));
+        // 16-row wave tiles while they fit one wave per SIMD (972 waves at config 2), 32-row ones beyond
+        const long w16 = (long)((M + 15) / 16) * ((n_tiles + rows16 - 1) / rows16);
+        MCG_HIP(mcg_gemm16_launch(g, rows16, s, w16 <= 1280 ? 1 : 2));
         return MCG_OK;
     }
     if (Bp16x3) {            // f32x6: three-part operands on the bf16 pipe, fp32-accurate
@@ -1655,10 +1657,9 @@ int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s, bool keep
         hipLaunchKernelGGL(k_combine_agg_t, dim3(M), dim3(128), 0, s, pl->P, pl->node_slots, pl->agg);
         MCG_HIP(hipGetLastError());
     }
-    // node_mlp: h + W4 silu(W3 [h | agg] + b3) + b4   (egnn.py:30-34,66-67).  16-row wave tiles of 3 column tiles
-    // balance these two GEMMs on 1024 SIMDs for M up to ~2.3k rows (972 waves at config 2); beyond that the
-    // 32-row kernel's cost model takes over.
-    const int r16 = (f32 && M <= 2304) ? 3 : 0;
+    // node_mlp: h + W4 silu(W3 [h | agg] + b3) + b4   (egnn.py:30-34,66-67).  Wave tiles of 3 column tiles x 16 rows
+    // balance these two GEMMs on 1024 SIMDs at config 2 (972 waves); larger batches take 32-row tiles (gemm()).
+    const int r16 = f32 ? 3 : 0;
     if (int e = gemm(pl->h, HP, H, gather ? pl->U : pl->agg, HP, H, Nl.w3_Bp, Nl.b3, nullptr, 0, pl->t1, HP, M, NT, HP, MCG_ACT_SILU, s,
                      lp ? Nl.w3_Bp16 : nullptr, x6g ? Nl.w3_Bp16x3 : nullptr, nullptr, gather ? 3 : r16, gather)) return e;
     if (int e = gemm(pl->t1, HP, H, nullptr, 0, 0, Nl.w4_Bp, Nl.b4, pl->h, HP, pl->h2, HP, M, NT, HP, MCG_ACT_NONE, s,

@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256) void mcg_gemm_kernel(McgGemmArgs p) {
 // N = 432: 756 waves of 840 MFMAs = 11.2 us of serial chain on 74 % of the SIMDs); 16 x 3 tiles give 972 waves
 // of 630 MFMAs (8.4 us), 16 x 6 the same for N = 864.  Same operand packs, ring discipline and transposed
 // accumulators as mcg_gemm_kernel.  GATHER: segment-2 rows are read as the sum of two rows (see a2_rows).
-template <int RN, bool GATHER, int RING = 3>
+template <int RN, bool GATHER, int MR = 1, int RING = 3>      // MR row tiles of 16 per wave (1: 16-row wave tiles, 2: 32-row)
 __global__ __launch_bounds__(256) void mcg_gemm16_kernel(McgGemmArgs p) {
     if ((int)blockIdx.x >= p.gemm_blocks) { mcg_gemm_side_job(p, (int)blockIdx.x - p.gemm_blocks); return; }
     const int lane = threadIdx.x & 63;
@@ -618,11 +618,15 @@ __global__ __launch_bounds__(256) void mcg_gemm16_kernel(McgGemmArgs p) {
     const int g = lane >> 4, c = lane & 15;
     const int wave_cols = (p.n_tiles + RN - 1) / RN;
     const int wlin = MCG_GEMM_BLOCK(blockIdx.x, p.gemm_blocks) * 4 + wid;
-    if (wlin >= ((p.M + 15) / 16) * wave_cols) return;
-    const int row0 = (wlin / wave_cols) * 16;
+    if (wlin >= ((p.M + 16 * MR - 1) / (16 * MR)) * wave_cols) return;
+    const int row0 = (wlin / wave_cols) * 16 * MR;
     const int nt0 = (wlin % wave_cols) * RN;
-    const int orow = row0 + c;
-    const int rA = orow < p.M ? orow : p.M - 1;           // clamp: results of padded rows are dropped
+    int orow[MR], rA[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        orow[m] = row0 + 16 * m + c;
+        rA[m] = orow[m] < p.M ? orow[m] : p.M - 1;        // clamp: results of padded rows are dropped
+    }
     bool nvalid[RN];
     int ncl[RN];
 #pragma unroll
@@ -630,46 +634,59 @@ __global__ __launch_bounds__(256) void mcg_gemm16_kernel(McgGemmArgs p) {
         nvalid[n] = nt0 + n < p.n_tiles;
         ncl[n] = nvalid[n] ? n : 0;
     }
-    f32x4 acc[RN];
+    f32x4 acc[MR][RN];
 #pragma unroll
-    for (int n = 0; n < RN; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 ebias[RN], eres[RN];
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < RN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ebias[RN], eres[MR][RN];
 #pragma unroll
     for (int n = 0; n < RN; ++n) {
         const int col = (nt0 + ncl[n]) * 16 + 4 * g;
         ebias[n] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        eres[n] = (p.resid && orow < p.M && col + 3 < p.n_store) ? *reinterpret_cast<const f32x4*>(p.resid + (size_t)orow * p.ldr + col)
-                                                                 : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+            eres[m][n] = (p.resid && orow[m] < p.M && col + 3 < p.n_store) ? *reinterpret_cast<const f32x4*>(p.resid + (size_t)orow[m] * p.ldr + col)
+                                                                            : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const float* bseg = p.Bp;
-    // one K segment; TWO: activation rows are the sum of two rows (row indices ra, rb)
-    auto segment = [&](auto two_tag, const float* A, int K, int lda, int ra, int rb) {
+    // one K segment; TWO: activation rows are the sum of two rows (row indices ra[m], rb[m])
+    auto segment = [&](auto two_tag, const float* A, int K, int lda, const int (&ra)[MR], const int (&rb)[MR]) {
         constexpr bool TWO = decltype(two_tag)::value;
         const int groups = K / 16;
         const size_t gstride = (size_t)p.n_tiles * 256;
         if (groups > 0) {
-            f32x4 Ar[RING], Ar2[RING], Br[RING][RN];
+            f32x4 Ar[RING][MR], Ar2[RING][MR], Br[RING][RN];
             const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, 0xffffffff, 0x00020000);
             const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bseg), 0, 0xffffffff, 0x00020000);
-            const unsigned oa = (unsigned)(ra * lda + 4 * g) * 4u, oa2 = (unsigned)(rb * lda + 4 * g) * 4u;
+            unsigned oa[MR], oa2[MR];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) { oa[m] = (unsigned)(ra[m] * lda + 4 * g) * 4u; oa2[m] = (unsigned)(rb[m] * lda + 4 * g) * 4u; }
             unsigned obn[RN];
 #pragma unroll
             for (int n = 0; n < RN; ++n) obn[n] = (unsigned)((nt0 + ncl[n]) * 256 + lane * 4) * 4u;
             const int gbytes = p.n_tiles * 256 * 4;
             auto load_group = [&](int slot, int q) {
                 q = q < groups ? q : groups - 1;
-                Ar[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)oa, 64 * q, 0));
-                if (TWO) Ar2[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)oa2, 64 * q, 0));
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    Ar[slot][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)oa[m], 64 * q, 0));
+                    if (TWO) Ar2[slot][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)oa2[m], 64 * q, 0));
+                }
 #pragma unroll
                 for (int n = 0; n < RN; ++n)
                     Br[slot][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)obn[n], q * gbytes, 0));
             };
             auto compute = [&](int slot) {
-                const f32x4 a = TWO ? Ar[slot] + Ar2[slot] : Ar[slot];
+                f32x4 a[MR];
+#pragma unroll
+                for (int m = 0; m < MR; ++m) a[m] = TWO ? Ar[slot][m] + Ar2[slot][m] : Ar[slot][m];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int n = 0; n < RN; ++n) acc[n] = mcg_mfma(Br[slot][n][s], a[s], acc[n]);
+                    for (int m = 0; m < MR; ++m)
+#pragma unroll
+                        for (int n = 0; n < RN; ++n) acc[m][n] = mcg_mfma(Br[slot][n][s], a[m][s], acc[m][n]);
             };
 #pragma unroll
             for (int i = 0; i < RING; ++i) load_group(i, i);
@@ -689,18 +706,28 @@ __global__ __launch_bounds__(256) void mcg_gemm16_kernel(McgGemmArgs p) {
         const float* bt = bseg + (size_t)groups * gstride + (size_t)nt0 * 64 + lane;
         for (int st = 0; st < tail; ++st) {
             const int k = groups * 16 + 4 * st + g;                    // k = 16Q + 4st + g
-            float av = A[(size_t)ra * lda + k];
-            if (TWO) av += A[(size_t)rb * lda + k];
+            float av[MR];
 #pragma unroll
-            for (int n = 0; n < RN; ++n) acc[n] = mcg_mfma(bt[(size_t)st * p.n_tiles * 64 + ncl[n] * 64], av, acc[n]);
+            for (int m = 0; m < MR; ++m) {
+                av[m] = A[(size_t)ra[m] * lda + k];
+                if (TWO) av[m] += A[(size_t)rb[m] * lda + k];
+            }
+#pragma unroll
+            for (int n = 0; n < RN; ++n) {
+                const float b = bt[(size_t)st * p.n_tiles * 64 + ncl[n] * 64];
+#pragma unroll
+                for (int m = 0; m < MR; ++m) acc[m][n] = mcg_mfma(b, av[m], acc[m][n]);
+            }
         }
         bseg += mcg_pack4_floats(K, p.n_tiles);
     };
     if (p.K1 > 0) segment(std::false_type{}, p.A1, p.K1, p.lda1, rA, rA);
     if (p.K2 > 0) {
         if (GATHER) {
-            const int2 sl = p.a2_rows[rA];
-            segment(std::true_type{}, p.A2, p.K2, p.lda2, sl.x, sl.y);
+            int sa[MR], sb[MR];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) { const int2 sl = p.a2_rows[rA[m]]; sa[m] = sl.x; sb[m] = sl.y; }
+            segment(std::true_type{}, p.A2, p.K2, p.lda2, sa, sb);
         } else {
             segment(std::false_type{}, p.A2, p.K2, p.lda2, rA, rA);
         }
@@ -709,45 +736,48 @@ __global__ __launch_bounds__(256) void mcg_gemm16_kernel(McgGemmArgs p) {
     for (int n = 0; n < RN; ++n) {
         if (!nvalid[n]) continue;
         const int col = (nt0 + n) * 16 + 4 * g;
-        if (col >= p.n_store || orow >= p.M) continue;
-        f32x4 v = acc[n] + ebias[n];
-        if (p.act == MCG_ACT_SILU) {
+        if (col >= p.n_store) continue;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = mcg_silu(v[r]);
-        } else if (p.act == MCG_ACT_RELU) {
+        for (int m = 0; m < MR; ++m) {
+            if (orow[m] >= p.M) continue;
+            f32x4 v = acc[m][n] + ebias[n];
+            if (p.act == MCG_ACT_SILU) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        }
-        v += eres[n];
-        float* dst = p.C + (size_t)orow * p.ldc + col;
-        if (col + 3 < p.n_store) {
-            *reinterpret_cast<f32x4*>(dst) = v;
-        } else {
+                for (int r = 0; r < 4; ++r) v[r] = mcg_silu(v[r]);
+            } else if (p.act == MCG_ACT_RELU) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (col + r < p.n_store) dst[r] = v[r];
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            v += eres[m][n];
+            float* dst = p.C + (size_t)orow[m] * p.ldc + col;
+            if (col + 3 < p.n_store) {
+                *reinterpret_cast<f32x4*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (col + r < p.n_store) dst[r] = v[r];
+            }
         }
     }
 }
 
-// launcher of the 16-row variant.  rn in {2, 3, 6}; the optional side job adds ceil(side_M * 4 / 256) workgroups.
-static inline hipError_t mcg_gemm16_launch(McgGemmArgs a, int rn, hipStream_t s) {
+// launcher: rn in {2, 3, 6} column tiles and mr in {1, 2} row tiles of 16 per wave; the optional side job adds
+// ceil(side_M * 4 / 256) workgroups.
+static inline hipError_t mcg_gemm16_launch(McgGemmArgs a, int rn, hipStream_t s, int mr = 1) {
     if (a.M <= 0) return hipSuccess;
-    const long waves = (long)((a.M + 15) / 16) * ((a.n_tiles + rn - 1) / rn);
+    const long waves = (long)((a.M + 16 * mr - 1) / (16 * mr)) * ((a.n_tiles + rn - 1) / rn);
     a.gemm_blocks = (int)((waves + 3) / 4);
     const int side = a.side_x ? (a.side_M * 4 + 255) / 256 : 0;
     const dim3 grid((unsigned)(a.gemm_blocks + side));
     const bool gather = a.a2_rows != nullptr && a.K2 > 0;
-    if (rn == 6) {
-        if (gather) hipLaunchKernelGGL((mcg_gemm16_kernel<6, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((mcg_gemm16_kernel<6, false>), grid, dim3(256), 0, s, a);
-    } else if (rn == 3) {
-        if (gather) hipLaunchKernelGGL((mcg_gemm16_kernel<3, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((mcg_gemm16_kernel<3, false>), grid, dim3(256), 0, s, a);
-    } else {
-        if (gather) hipLaunchKernelGGL((mcg_gemm16_kernel<2, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((mcg_gemm16_kernel<2, false>), grid, dim3(256), 0, s, a);
-    }
+#define MCG_G16(RN_, G_, MR_) hipLaunchKernelGGL((mcg_gemm16_kernel<RN_, G_, MR_>), grid, dim3(256), 0, s, a)
+    if (mr == 2) {
+        if (rn == 3) { if (gather) MCG_G16(3, true, 2); else MCG_G16(3, false, 2); }
+        else { if (gather) MCG_G16(2, true, 2); else MCG_G16(2, false, 2); }
+    } else if (rn == 6) { if (gather) MCG_G16(6, true, 1); else MCG_G16(6, false, 1); }
+    else if (rn == 3) { if (gather) MCG_G16(3, true, 1); else MCG_G16(3, false, 1); }
+    else { if (gather) MCG_G16(2, true, 1); else MCG_G16(2, false, 1); }
+#undef MCG_G16
     return hipGetLastError();
 }
 

@@ -209,3 +209,18 @@ def test_ifm_merge_oracle_matches_reference_golden():
                                 torch.tensor(g["rotation"]), int(g["z_known"].shape[1]))
     assert torch.equal(fm, torch.tensor(g["fixed_mask"]))
     assert float((zk - torch.tensor(g["z_known"])).abs().max()) <= 1e-6
+
+
+def test_div100_three_fma_form_equals_ieee_division(tmp_path):
+    """`mcg_div100` (x * fl(0.01) + one residual correction, csrc/mcg_common.h) against x / 100.0f on every 61st fp32
+    bit pattern (the full walk is `tools/native/div100_check.c` with stride 1): bit-identical in the working range."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "div100_check")
+    src = os.path.join(REPO, "tools", "native", "div100_check.c")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", src, "-o", exe, "-lm"], check=True)
+    r = subprocess.run([exe, "61"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout
+    assert " 0 of them" in r.stdout
