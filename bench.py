@@ -272,7 +272,9 @@ def spawn_ranks(n):
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < n:
+    # (MCG_DIST_BACKEND=gloo: dry run of the N-rank control flow with the ranks sharing the GPUs that exist - labelled
+    #  `dist_backend: gloo` in the line, never a scaling measurement)
+    if have < n and os.environ.get("MCG_DIST_BACKEND") != "gloo":
         sys.stderr.write(f"bench.py: --gpus {n} but this box has {have} GPU(s); refusing to report a smaller run\n")
         sys.exit(3)
     s = socket.socket()
@@ -415,10 +417,12 @@ def main():
             "config": {"workload": f"{cfg_label}: n_samples={B}/GPU, {args.n_atoms}"
                                    f"{'+-' + str(args.variance) if args.variance else ''} heavy atoms, "
                                    f"diffusion_steps={args.diffusion_steps}, " + mode_text,
-                       "parallelism": f"batch-sharded x{world}, RCCL all_gather at end" if world > 1 else "single GPU",
+                       "parallelism": (f"batch-sharded x{world}, " + ("RCCL" if backend == "nccl" else backend + " (dry run, ranks share the GPU)")
+                                       + " all_gather at end") if world > 1 else "single GPU",
                        "edge_rows_per_wave": 16 * plan.edge_mt, "real_edges": plan.n_real_edges,
                        "real_nodes": plan.n_real_nodes},
             "dist_world_size": dist.get_world_size() if use_dist else 1,
+            "dist_backend": (dist.get_backend() if use_dist else None),
             "timed_region": "MLConformerGenerator.generate_conformers_sharded: size draw, sampler, hand-off, GCN, bond "
                             "write-back + validity proxy, gather, D2H, molecule records",
             "validity": "`value` counts every molecule that went through the whole public path (raw); trained weights and "

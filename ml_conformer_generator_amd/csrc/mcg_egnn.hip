@@ -249,13 +249,13 @@ __device__ __forceinline__ void edge_epilogue_wg(const EdgeArgs& p, const WgSums
                                                  float* sl) {
     const int g = lane >> 4, c = lane & 15;
     float part[4] = {0.f, 0.f, 0.f, 0.f};
+    (void)b2p;                                                  // (the bias already sits in the accumulators: they start from it)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const float b2 = b2p[nt * 16 + c];
         const float wv = wvp[nt * 16 + c];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float m = mcg_silu(acc[0][nt][r] + b2);      // second Linear + SiLU (egnn.py:26-27)
+            const float m = mcg_silu(acc[0][nt][r]);           // second Linear (+ bias, see k_edge_lds) + SiLU (egnn.py:26-27)
             acc[0][nt][r] = m;
             part[r] = fmaf(wv, m, part[r]);
         }
@@ -413,7 +413,12 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) {
+            // WGC: the accumulators START from the second layer's bias (one load per column tile here instead of 108
+            // VALU adds in the epilogue, where every VALU instruction costs a matrix-pipe slot)
+            const float b0 = WGC ? p.b2[nt * 16 + c] : 0.f;
+            acc[mt][nt] = (f32x4){b0, b0, b0, b0};
+        }
 
     // operand addresses: buffer descriptor + 32-bit lane offset + scalar group offset (no 64-bit VALU adds per load)
     const __amdgpu_buffer_rsrc_t rs_pab = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pab), 0, 0xffffffff, 0x00020000);
