@@ -150,8 +150,9 @@ def main():
                 flag = "" if r >= MIN_RATIO else ("   <-- BLIND" if required else "   (informational)")
                 bad += required and r < MIN_RATIO
                 print(f"    {label:22s} {r:12.1f} x tolerance{flag}")
-                worst = r if worst is None else min(worst, r)
-            print(f"    -> least visible mutation: {worst:.1f} x tolerance")
+                if required:
+                    worst = r if worst is None else min(worst, r)
+            print(f"    -> least visible required mutation: {worst:.1f} x tolerance")
     print("PASS" if not bad else f"FAIL: {bad} blind spot(s)")
     return 1 if bad else 0
 
