@@ -10,7 +10,10 @@
  * read from the environment (MCG_GRAPH, MCG_X6_GEMM, MCG_WG_SUMS and MCG_NS_MAX_TILES once, on first use, and then cached for the
  * life of the process; the others at every plan creation / launch) - none is needed for normal operation:
  *   MCG_GRAPH=0          plain launches instead of the captured HIP graph per denoiser call
- *   MCG_NS_MAX_TILES=n   largest batch (16-row edge tiles) that takes the column-split latency edge kernel (512)
+ *   MCG_NS_MAX_TILES=n   largest batch (16-row edge tiles) that takes the stand-alone column-split edge kernel when a
+ *                        plan has no workgroup-level tables (512)
+ *   MCG_TAIL=0|n|-1      four-tile workgroups of the throughput edge kernel: all / the first n / none (default: every
+ *                        complete round of the chip), read at plan creation
  *   MCG_EDGE_MT=1|2      rows/16 per wave of the exact-fp32 edge kernel for new plans
  *   MCG_SPLIT=n          molecule ranges (HIP streams) per plan, overriding the library's choice
  *   MCG_WG_SUMS=0        per-wave partial sums + combine / coordinate-update launches instead of the workgroup-level
@@ -69,8 +72,10 @@ int mcg_plan_create(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_
  * mcg_egnn_dynamics; 0 = the library's choice: 2 from 8 192 edge tiles on, 1 below) given by the caller. */
 int mcg_plan_create_ranges(int B, int N, const int32_t* n_nodes_host, int edge_mt, int n_ranges, mcg_plan** out);
 void mcg_plan_destroy(mcg_plan* p);
-/* Edge-kernel choice: -1 auto (the column-split latency kernel when the batch has <= 512 edge tiles,
- * else the throughput kernel), 0 = always throughput, 1 = always latency (needs edge_mt 1). */
+/* Edge-kernel choice (exact-fp32 mode, edge_mt 1): -1 auto - the throughput kernel, whose workgroups take four 16-row
+ * tiles each for every complete round of the chip and ONE tile each (columns split over the 4 waves) for the rest, i.e.
+ * for the whole of a small batch; 0 = four-tile workgroups only; 1 = the stand-alone column-split kernel with per-wave
+ * partial sums (the fallback for plans without workgroup-level tables). */
 int mcg_plan_set_latency_mode(mcg_plan* p, int mode);
 /* info[8] = {real nodes, real edges, edge_mt, edge waves, partial slots, B, N, 16-row edge tiles} */
 int mcg_plan_info(const mcg_plan* p, int32_t* info_host);

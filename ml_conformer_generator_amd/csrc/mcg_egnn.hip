@@ -88,6 +88,8 @@ struct EdgeArgs {
     const int4* wg_info;    // per workgroup: {first global slot, slots, ws0 of its 4 waves (8 bits each), nseg of its 4 waves
                             // (8 bits each)} - ONE 16-byte scalar load per workgroup
     float* U;
+    int n_full_wg;          // workgroups [0, n_full_wg) take four tiles each (LDS-staged body), the rest ONE tile (quarter-tile body)
+    const float* Bp4;       // the same second-layer weights as B-pack4 (mcg_gemm.h): 16 B per lane and 16-k group
 };
 
 template <int MT>
@@ -96,8 +98,9 @@ struct RowInfo {            // per-lane facts about its A-operand rows (row = ti
     float d2[MT], d02[MT], ux[MT], uy[MT], uz[MT];
 };
 
-template <int MT, bool EQUIV>
-__device__ __forceinline__ void edge_decode(const EdgeArgs& p, int wave, bool live, int c, RowInfo<MT>& R) {
+// (i, j, segment) of the lane's A-operand rows
+template <int MT>
+__device__ __forceinline__ void edge_decode_ij(const EdgeArgs& p, int wave, bool live, int c, RowInfo<MT>& R) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int tile = wave * MT + mt;
@@ -105,13 +108,23 @@ __device__ __forceinline__ void edge_decode(const EdgeArgs& p, int wave, bool li
         // one 8-byte load instead of the tile -> molecule -> (row_off, n, node_off) -> division chain: the row
         // decode sits at the head of every workgroup's dependent-load chain and nothing overlaps it.
         // .y carries j in its low 24 bits and the row's segment (rank of node i among the nodes that own rows
-        // of this unit, < 16 by plan construction) above them.
+        // of this unit, < 16 by plan construction) above them.  (Read as ONE 64-bit word: as an int2 whose .y is
+        // only used when .x >= 0, hipcc emits two dependent 4-byte loads - two memory round trips.)
         int vi = 0, vj = 0, sg = -1;
         if (live && tile < p.n_mtiles) {
-            const int2 ij = p.row_ij[r];
-            if (ij.x >= 0) { vi = ij.x; vj = ij.y & 0xffffff; sg = ij.y >> 24; }
+            const long long raw = reinterpret_cast<const long long*>(p.row_ij)[r];
+            const int ix = (int)raw, iy = (int)(raw >> 32);
+            if (ix >= 0) { vi = ix; vj = iy & 0xffffff; sg = iy >> 24; }
         }
         R.ni[mt] = vi; R.nj[mt] = vj; R.seg[mt] = sg;
+    }
+}
+// squared distances (current and at network input) and, for the coordinate head, the unit vectors of the rows
+template <int MT, bool EQUIV>
+__device__ __forceinline__ void edge_decode_x(const EdgeArgs& p, RowInfo<MT>& R) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int vi = R.ni[mt], vj = R.nj[mt];
         const f32x4 xi = *reinterpret_cast<const f32x4*>(p.x + (size_t)vi * 4);
         const f32x4 xj = *reinterpret_cast<const f32x4*>(p.x + (size_t)vj * 4);
         const f32x4 yi = *reinterpret_cast<const f32x4*>(p.x0 + (size_t)vi * 4);
@@ -127,6 +140,11 @@ __device__ __forceinline__ void edge_decode(const EdgeArgs& p, int wave, bool li
             R.ux[mt] = R.uy[mt] = R.uz[mt] = 0.f;
         }
     }
+}
+template <int MT, bool EQUIV>
+__device__ __forceinline__ void edge_decode(const EdgeArgs& p, int wave, bool live, int c, RowInfo<MT>& R) {
+    edge_decode_ij<MT>(p, wave, live, c, R);
+    edge_decode_x<MT, EQUIV>(p, R);
 }
 
 // Epilogue shared by both edge kernels.  C/D layout: column = 16*nt + c, row = 4*g + r of tile mt.
@@ -370,6 +388,243 @@ __device__ __forceinline__ void edge_epilogue_wg(const EdgeArgs& p, const WgSums
     }
 }
 
+// ---- quarter-tile body of the throughput kernel: ONE 16-row tile per workgroup, its 27 column tiles split over the
+// 4 waves (7, 7, 7, 6).  It serves the last, partly filled round of the chip (mcg_plan::n_full_wg): there the four-tile
+// body leaves 1/4 .. 3/4 of the SIMDs idle while each busy one walks a whole tile's chain of 2 835 MFMAs; here the chain
+// is 4x shorter and 4x more SIMDs work.  Differences from the four-tile body, all following from "a wave needs only ITS
+// columns of W2 and every wave needs the SAME activation rows":
+//   * B fragments come straight from L2 into a three-group register ring (B-pack4: one 16-byte load per lane feeds the
+//     4 k-steps of a column tile) - nothing to share through LDS, no ds_reads between the MFMAs;
+//   * the layer-1 finish (A operand: 16 rows x 16 k per group) is generated ONCE per workgroup, waves 0..2 one group
+//     each per super-group of three, and published through a double-buffered LDS ring: one barrier per 48 k;
+//   * the gate / coordinate-head dot product needs one cross-wave exchange.
+// Accumulation order over k (bias first, then k ascending) is that of the four-tile body: m_ij is bit-identical.
+constexpr int QT = 7;                               // column tiles per wave: nt = 7 * wid + i (wave 3: tile 26 twice)
+constexpr int Q_ABUF = 2 * 3 * 256;                 // floats: [2][3 groups][64 lanes] x 16 B
+constexpr int Q_TAILB = 26 * NT * 256;              // float offset of the tail k-step inside a B-pack4 (mcg_pack_b4)
+
+template <bool EQUIV>
+__device__ __forceinline__ void edge_quarter_body(const EdgeArgs& p, int unit, int tile, float* lds) {
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15;
+#ifdef MCG_QX_STAMP
+    unsigned long long ts[6];
+    ts[0] = __builtin_amdgcn_s_memtime();
+#endif
+    RowInfo<1> R;
+    edge_decode_ij<1>(p, tile, true, c, R);
+#ifdef MCG_QX_STAMP
+    { int dummy = __builtin_amdgcn_readfirstlane(R.ni[0]); asm volatile("" :: "s"(dummy)); ts[1] = __builtin_amdgcn_s_memtime(); }
+#endif
+    const int4 wi = p.wg_info[unit];
+    const int sbase = __builtin_amdgcn_readfirstlane(wi.x), nseg = __builtin_amdgcn_readfirstlane(wi.y);
+    float* abuf = lds;
+    float* xchg = lds + Q_ABUF;                     // [4 waves][16 rows] partial dot products
+
+    const __amdgpu_buffer_rsrc_t rs_pab = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pab), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wd), 0, (HP + 32) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wd0), 0, (HP + 32) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Bp4), 0, (Q_TAILB + NT * 64) * 4, 0x00020000);
+    const unsigned oa = (unsigned)(R.ni[0] * (2 * HP) + 4 * g) * 4u;
+    const unsigned ob = (unsigned)(R.nj[0] * (2 * HP) + HP + 4 * g) * 4u;
+    const unsigned ow = (unsigned)(4 * g) * 4u;
+    auto ld4 = [](const __amdgpu_buffer_rsrc_t& r, unsigned v, int so) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)v, so, 0));
+    };
+    // A operand of group gq for this lane's (row c, k = 16 gq + 4 g + s)
+    struct AIn { f32x4 va, vb, wdv, w0v; };
+    auto a_load = [&](int gq, AIn& in) {
+        in.va = ld4(rs_pab, oa, 64 * gq); in.vb = ld4(rs_pab, ob, 64 * gq);
+        in.wdv = ld4(rs_wd, ow, 64 * gq); in.w0v = ld4(rs_w0, ow, 64 * gq);
+    };
+    auto a_load_tail = [&](AIn& in) {               // k = 416 + g: one k-step
+        constexpr int K0 = 16 * (H / 16);
+        in.va = (f32x4){p.pab[(size_t)R.ni[0] * (2 * HP) + K0 + g], 0.f, 0.f, 0.f};
+        in.vb = (f32x4){p.pab[(size_t)R.nj[0] * (2 * HP) + HP + K0 + g], 0.f, 0.f, 0.f};
+        in.wdv = (f32x4){p.wd[K0 + g], 0.f, 0.f, 0.f};
+        in.w0v = (f32x4){p.wd0[K0 + g], 0.f, 0.f, 0.f};
+    };
+    auto a_publish = [&](AIn& in, int buf) {
+        asm volatile("" : "+v"(in.va), "+v"(in.vb), "+v"(in.wdv), "+v"(in.w0v));      // (keeps the arithmetic HERE, not behind the loads)
+        f32x4 a;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[s] = mcg_silu(fmaf(in.w0v[s], R.d02[0], fmaf(in.wdv[s], R.d2[0], in.va[s] + in.vb[s])));
+        *reinterpret_cast<f32x4*>(abuf + ((buf * 3 + wid) * 64 + lane) * 4) = a;
+    };
+    // Load order = the order the prologue needs the data in (the vector-memory counter retires in order): the first
+    // super-group's A inputs and the coordinates right behind the row decode, then the per-column parameters, then the
+    // 21 B fragments of the ring (only the first 7 are needed for the first MFMAs).
+    AIn ain;
+    if (wid < 3) a_load(wid, ain);
+    edge_decode_x<1, EQUIV>(p, R);
+    int ntw[QT];                                    // own column tiles (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < QT; ++i) ntw[i] = min(QT * wid + i, NT - 1);
+    // B ring: group q of the wave's 7 column tiles = 7 x 16 B per lane
+    f32x4 Bq[3][QT];
+    auto loadB = [&](int q, f32x4 (&dst)[QT], int i) { dst[i] = ld4(rs_b, (unsigned)lane * 16u, (q * NT + ntw[i]) * 1024); };
+    auto loadB_tail = [&](f32x4 (&dst)[QT], int i) {
+        dst[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_b, (int)(lane * 4), (Q_TAILB + ntw[i] * 64) * 4, 0));
+    };
+    f32x4 acc[QT];
+    float wvr[QT];
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+        const float b0 = p.b2[ntw[i] * 16 + c];     // the accumulators start from the second layer's bias
+        const float w = p.wv[ntw[i] * 16 + c];
+        wvr[i] = (QT * wid + i < NT) ? w : 0.f;     // (wave 3 computes column tile 26 twice; the copy counts for nothing)
+        acc[i] = (f32x4){b0, b0, b0, b0};
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < QT; ++i) loadB(j, Bq[j], i);
+    if (wid < 3) a_publish(ain, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+#ifdef MCG_QX_STAMP
+    ts[2] = __builtin_amdgcn_s_memtime();
+#endif
+
+    // one super-group = groups 3 SG .. 3 SG + 2.  MODE 0: regular (refill the ring with groups 3 SG + 3 ..),
+    // 1: SG = 7 (the refill of slot 2 is the tail k-step), 2: SG = 8 (groups 24, 25 and the tail k-step; no refill)
+    auto super = [&](auto mode_tag, int SG) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        f32x4 Aq[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Aq[j] = *reinterpret_cast<const f32x4*>(abuf + (((SG & 1) * 3 + j) * 64 + lane) * 4);
+#ifndef MCG_QX_NOAGEN
+        if (MODE < 2 && wid < 3) {
+            if (MODE == 1 && wid == 2) a_load_tail(ain);
+            else a_load(3 * (SG + 1) + wid, ain);
+        }
+#endif
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const bool tail_step = MODE == 2 && j == 2;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (tail_step && s > 0) break;
+#pragma unroll
+                for (int i = 0; i < QT; ++i) {
+                    acc[i] = mcg_mfma(Aq[j][s], Bq[j][i][s], acc[i]);
+#ifndef MCG_QX_NOB
+                    if (s == 3 && MODE < 2) {
+                        // the fragment is consumed: refill it three groups ahead, right behind its last MFMA
+                        if (MODE == 1 && j == 2) loadB_tail(Bq[j], i);
+                        else loadB(3 * (SG + 1) + j, Bq[j], i);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+#endif
+                }
+                if (s < 3 || MODE == 2) __builtin_amdgcn_sched_group_barrier(0x008, QT, 0);
+            }
+#ifndef MCG_QX_NOAGEN
+            if (j == 0 && MODE < 2 && wid < 3) a_publish(ain, (SG + 1) & 1);
+#endif
+        }
+#ifndef MCG_QX_NOBAR
+        if (MODE < 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+        }
+#endif
+    };
+#pragma unroll 1
+    for (int SG = 0; SG < 7; ++SG) super(std::integral_constant<int, 0>{}, SG);
+    super(std::integral_constant<int, 1>{}, 7);
+    super(std::integral_constant<int, 2>{}, 8);
+#ifdef MCG_QX_STAMP
+    { float dummy = acc[0][0]; asm volatile("" :: "v"(dummy)); ts[3] = __builtin_amdgcn_s_memtime(); }
+#endif
+
+    // ---- epilogue on the wave's own column tiles
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < QT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float m = mcg_silu(acc[i][r]);                    // second Linear (+ bias) + SiLU (egnn.py:26-27)
+            acc[i][r] = m;
+            part[r] = fmaf(wvr[i], m, part[r]);
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        part[r] = mcg_row16_sum(part[r]);
+        if (c == 0) xchg[wid * 16 + 4 * g + r] = part[r];
+    }
+    __syncthreads();
+#ifdef MCG_QX_STAMP
+    ts[4] = __builtin_amdgcn_s_memtime();
+#endif
+    float dot[4];
+    int rseg[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        dot[r] = ((xchg[row] + xchg[16 + row]) + xchg[32 + row]) + xchg[48 + row];     // fixed wave order
+        rseg[r] = __shfl(R.seg[0], row, 64);
+    }
+    if (EQUIV) {
+        if (wid != 0) return;
+        // sums of trans = coord_diff * phi * edge_mask (egnn.py:124-127); /100 is applied with the update
+        float tx[4], ty[4], tz[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * g + r;
+            tx[r] = __shfl(R.ux[0], row, 64) * dot[r];
+            ty[r] = __shfl(R.uy[0], row, 64) * dot[r];
+            tz[r] = __shfl(R.uz[0], row, 64) * dot[r];
+        }
+        for (int sg = 0; sg < nseg; ++sg) {
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (rseg[r] == sg) { sx += tx[r]; sy += ty[r]; sz += tz[r]; }
+            sx = mcg_group4_sum(sx); sy = mcg_group4_sum(sy); sz = mcg_group4_sum(sz);
+            if (lane == 0) {
+                float* dst = p.U + (size_t)(sbase + sg) * 4;
+                dst[0] = sx; dst[1] = sy; dst[2] = sz; dst[3] = 0.f;
+            }
+        }
+        return;
+    }
+    // GCL: gate (att_mlp, egnn.py:36,48), then the segmented gate-scaled sum over the tile's rows on the matrix pipe
+    // (edge_epilogue): segment s lands in register s/4 of lane group s%4
+    const int sc = (c >> 2) + 4 * (c & 3);
+    float sel[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sel[r] = rseg[r] == sc ? mcg_sigmoid(dot[r] + p.bv) : 0.f;
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+        f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) d = mcg_mfma(sel[t], acc[i][t], d);
+        acc[i] = d;
+    }
+    // one row of U per atom of the tile, already divided by the normalisation factor (egnn.py:435); a wave writes its
+    // 7 x 64 B of every row (one predicated block per register index, see edge_epilogue_wg)
+    const int n_own = wid == 3 ? QT - 1 : QT;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (g + 4 * r < nseg) {
+            float* row = p.U + (size_t)(sbase + g + 4 * r) * HP + (QT * wid) * 16 + c;
+#pragma unroll
+            for (int i = 0; i < QT; ++i)
+                if (i < n_own) row[i * 16] = mcg_div100(acc[i][r]);
+        }
+    }
+#ifdef MCG_QX_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ts[5] = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && (unit % 97) == 3 && p.n_rows == MCG_QX_STAMP)
+        printf("unit %d wave %d: decode %llu prologue %llu loop %llu dot+barrier %llu rest %llu total %llu\n", unit, wid,
+               ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4], ts[5] - ts[0]);
+#endif
+}
+
 // ---- throughput kernel: 4 waves per workgroup share the packed W2 through LDS -------------------
 // (its predecessor - one independent wave per workgroup with B fragments straight from L2 - reached 40 % of the
 //  fp32 MFMA peak: hipcc keeps only 6-10 loads in flight, less than an L2 latency)
@@ -394,7 +649,14 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
     // other placement is merely slower).  Remapping so that each XCD owns a CONTIGUOUS range of edge
     // tiles keeps the ~11 workgroups that share one molecule's Pab rows on one L2 (bijective form
     // for grids that are not a multiple of 8).
-    const int wg = mcg_xcd_remap(blockIdx.x, gridDim.x);
+    if constexpr (WGC) {
+        if ((int)blockIdx.x >= p.n_full_wg) {       // quarter-tile unit: one tile, columns split over the 4 waves
+            const int k = mcg_xcd_remap((int)blockIdx.x - p.n_full_wg, (int)gridDim.x - p.n_full_wg);
+            edge_quarter_body<EQUIV>(p, p.n_full_wg + k, 4 * p.n_full_wg + k, lds);
+            return;
+        }
+    }
+    const int wg = WGC ? mcg_xcd_remap(blockIdx.x, p.n_full_wg) : mcg_xcd_remap(blockIdx.x, gridDim.x);
     const int wave_raw = wg * 4 + wid;
     const bool live = wave_raw < p.n_waves;
     const int wave = live ? wave_raw : p.n_waves - 1;
@@ -1203,31 +1465,32 @@ __global__ void k_coord_update_t(const float* __restrict__ Px, const int* __rest
 }
 
 // Stand-alone consumers of the workgroup-level sums (debug hooks and the operand modes whose GEMM kernels cannot
-// gather): x += (Ux[s.x] + Ux[s.y]) / 100, and agg = U[s.x] + U[s.y].
-__global__ void k_coord_apply2(const float* __restrict__ Ux, const int2* __restrict__ slots2, int M, float* __restrict__ x) {
+// gather): x += (Ux[s.x] + .. + Ux[s.w]) / 100, and agg = U[s.x] + .. + U[s.w] (unused slots = the zero row).
+__global__ void k_coord_apply2(const float* __restrict__ Ux, const int4* __restrict__ slots2, int M, float* __restrict__ x) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int v = idx >> 2, comp = idx & 3;
     if (v >= M || comp == 3) return;
-    const int2 sl = slots2[v];
-    x[(size_t)v * 4 + comp] += (Ux[(size_t)sl.x * 4 + comp] + Ux[(size_t)sl.y * 4 + comp]) / NORM;
+    const int4 sl = slots2[v];
+    x[(size_t)v * 4 + comp] += (((Ux[(size_t)sl.x * 4 + comp] + Ux[(size_t)sl.y * 4 + comp]) + Ux[(size_t)sl.z * 4 + comp]) + Ux[(size_t)sl.w * 4 + comp]) / NORM;
 }
-__global__ __launch_bounds__(128) void k_gather_agg2(const float* __restrict__ U, const int2* __restrict__ slots2, float* __restrict__ agg) {
+__global__ __launch_bounds__(128) void k_gather_agg2(const float* __restrict__ U, const int4* __restrict__ slots2, float* __restrict__ agg) {
     const int v = blockIdx.x;
-    const int2 sl = slots2[v];
-    for (int col = threadIdx.x; col < HP; col += 128) agg[(size_t)v * HP + col] = U[(size_t)sl.x * HP + col] + U[(size_t)sl.y * HP + col];
+    const int4 sl = slots2[v];
+    for (int col = threadIdx.x; col < HP; col += 128)
+        agg[(size_t)v * HP + col] = ((U[(size_t)sl.x * HP + col] + U[(size_t)sl.y * HP + col]) + U[(size_t)sl.z * HP + col]) + U[(size_t)sl.w * HP + col];
 }
 
 // ------------------------------------------------------------------------------ output head
 // h_final = embedding_out(h) (first 8 of 12 channels kept), vel = (x - x0) with the masked
 // mean removed; padded slots of out[B,N,11] are zero  (egnn.py:398-399, :499-513).
 // `ux` / `slots2` (optional): the last block's coordinate update, still pending as workgroup-level sums
-// (x_final = x + (ux[s.x] + ux[s.y]) / 100, egnn.py:128-148).
+// (x_final = x + (ux[s.x] + .. + ux[s.w]) / 100, egnn.py:128-148).
 __global__ __launch_bounds__(512) void k_output(const float* __restrict__ h, const float* __restrict__ x,
                                                  const float* __restrict__ x0, const int* __restrict__ n_nodes,
                                                  const int* __restrict__ node_off, int N,
                                                  const float* __restrict__ out_w,  // [12][HP]
                                                  const float* __restrict__ out_b, float* __restrict__ out,
-                                                 const float* __restrict__ ux, const int2* __restrict__ slots2) {
+                                                 const float* __restrict__ ux, const int4* __restrict__ slots2) {
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int n = n_nodes[b];
@@ -1237,9 +1500,11 @@ __global__ __launch_bounds__(512) void k_output(const float* __restrict__ h, con
         const size_t v = (size_t)(v0 + i);
         f32x4 xv = *reinterpret_cast<const f32x4*>(x + v * 4);
         if (ux) {
-            const int2 sl = slots2[v];
+            const int4 sl = slots2[v];
             const f32x4 a = *reinterpret_cast<const f32x4*>(ux + (size_t)sl.x * 4), b = *reinterpret_cast<const f32x4*>(ux + (size_t)sl.y * 4);
-            xv[0] += (a[0] + b[0]) / NORM; xv[1] += (a[1] + b[1]) / NORM; xv[2] += (a[2] + b[2]) / NORM;
+            const f32x4 d = *reinterpret_cast<const f32x4*>(ux + (size_t)sl.z * 4), e = *reinterpret_cast<const f32x4*>(ux + (size_t)sl.w * 4);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) xv[k] += (((a[k] + b[k]) + d[k]) + e[k]) / NORM;
         }
         return xv - *reinterpret_cast<const f32x4*>(x0 + v * 4);
     };
@@ -1316,7 +1581,7 @@ int upload_i(const std::vector<int>& v, int** d) {
 
 struct EdgeLayer {      // second layer + head of an edge MLP, and its factorised first layer
     float *pab_Bp = nullptr, *pab_bias = nullptr, *wd = nullptr, *wd0 = nullptr;
-    float *w2_Bp = nullptr, *b2 = nullptr, *wv = nullptr;
+    float *w2_Bp = nullptr, *w2_Bp4 = nullptr, *b2 = nullptr, *wv = nullptr;
     float bv = 0.f;
     uint16_t *pab_Bp16 = nullptr, *w2_Bp16 = nullptr;     // bf16 operand packs
     uint16_t* w2_Bp16x3 = nullptr;                        // W2 as three bf16 parts, [k-block][part][nt][lane][8] (f32x6 mode)
@@ -1353,9 +1618,16 @@ struct mcg_plan {
           *P = nullptr, *Px = nullptr;
     // workgroup-level sums of the throughput edge kernel (MT = 1; see edge_epilogue_wg): one row per (workgroup, atom)
     bool wgc = false;                       // tables below are valid and every workgroup touches <= 16 atoms
-    int n_uslots = 0;                       // rows of U / Ux (+ one zero row at index n_uslots)
-    int4* wg_info = nullptr;
-    int2* node_slots2 = nullptr;            // per atom: its one or two rows of U (second = the zero row when unused)
+    struct UnitTables {
+        int n_units = 0, n_full_wg = 0;     // workgroups of the throughput kernel; the first n_full_wg take four tiles, the rest one
+        int n_uslots = 0;                   // rows of U / Ux (+ one zero row at index n_uslots)
+        int4* wg_info = nullptr;
+        int4* node_slots = nullptr;         // per atom: its one to four rows of U (unused = the zero row)
+        int max_span = 2;                   // most rows of U any atom has (3 / 4 only with quarter-tile units)
+    };
+    UnitTables ut[2];                       // [0]: the automatic split into four-tile and quarter-tile units,
+    bool have_alt = false;                  // [1]: four-tile units only (latency_mode 0), built when it differs from [0]
+    const UnitTables& units() const { return ut[(latency_mode == 0 && have_alt) ? 1 : 0]; }
     float *U = nullptr, *Ux = nullptr;
     bool x_pending = false;                 // host-side: Ux holds a coordinate update that has not been applied to x yet
     std::vector<void*> allocs;
@@ -1378,7 +1650,7 @@ struct mcg_plan {
     // plan-owned staging buffers instead and each call adds three small device-to-device copies around it.
     int key_changes = 0;
     float *xh_stage = nullptr, *ctx_stage = nullptr, *out_stage = nullptr;
-    int latency_mode = -1;                  // column-split edge kernel: -1 auto (small batches), 0 never, 1 always
+    int latency_mode = -1;                  // -1 auto; 0: four-tile units only; 1: the stand-alone column-split kernel (k_edge_ns)
 };
 
 namespace {
@@ -1410,6 +1682,10 @@ int build_edge_layer(mcg_egnn* m, EdgeLayer& L, const float* w1 /*[420][842]*/, 
     pack_B(buf, H, NT, [&](int n, int k) -> float { return n < H ? w2[(size_t)n * H + k] : 0.f; }, GROUP_LDS_FLOATS);
     if (int e = upload(buf, &L.w2_Bp)) return e;
     m->allocs.push_back(L.w2_Bp);
+    buf.clear();            // the same weights as B-pack4 (quarter-tile body of the edge kernel)
+    mcg_pack_b4(buf, H, NT, [&](int n, int k) -> float { return n < H ? w2[(size_t)n * H + k] : 0.f; });
+    if (int e = upload(buf, &L.w2_Bp4)) return e;
+    m->allocs.push_back(L.w2_Bp4);
     {   // bf16 operand packs of the same weights
         std::vector<uint16_t> b16;
         mcg_pack_b16(b16, H, 2 * NT, [&](int n, int k) -> float {
@@ -1523,7 +1799,9 @@ void launch_edge(bool equiv, const EdgeArgs& a, int n_waves, hipStream_t s) {
 static bool edge_latency_kernel(const mcg_plan* pl) {
     static int ns_max = -1;
     if (ns_max < 0) { const char* e = getenv("MCG_NS_MAX_TILES"); ns_max = e ? atoi(e) : 512; }
-    return pl->MT == 1 && (pl->latency_mode == 1 || (pl->latency_mode < 0 && pl->n_mtiles <= ns_max));
+    // (automatic mode: plans with workgroup-level tables run small batches on the quarter-tile units of the throughput
+    //  kernel instead - 17 / 30 us per launch at 176 / 351 tiles against 24 / 36 us for k_edge_ns)
+    return pl->MT == 1 && (pl->latency_mode == 1 || (pl->latency_mode < 0 && !pl->wgc && pl->n_mtiles <= ns_max));
 }
 // exact-fp32 throughput kernel with workgroup-level sums (writes pl->U / pl->Ux instead of per-wave partials)
 static bool edge_wgc(const mcg_egnn* m, const mcg_plan* pl) {
@@ -1540,9 +1818,11 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
     a.wv = L.wv; a.bv = L.bv; a.n_nodes = pl->n_nodes; a.node_off = pl->node_off; a.row_off = pl->row_off;
     a.B = pl->B; a.tile_mol = pl->tile_mol; a.row_ij = pl->row_ij; a.wave_poff = pl->wave_poff;
     a.n_rows = pl->n_rows; a.n_mtiles = pl->n_mtiles; a.n_waves = pl->n_waves; a.P = P;
-    a.wg_info = pl->wg_info; a.U = equiv ? pl->Ux : pl->U;
+    const mcg_plan::UnitTables& T = pl->units();
+    a.wg_info = T.wg_info; a.U = equiv ? pl->Ux : pl->U;
+    a.n_full_wg = T.n_full_wg; a.Bp4 = L.w2_Bp4;
     if (wgc) {
-        const int wgs = (pl->n_waves + 3) / 4;
+        const int wgs = T.n_units;
         if (equiv) hipLaunchKernelGGL((k_edge_lds<1, true, true>), dim3(wgs), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_edge_lds<1, false, true>), dim3(wgs), dim3(256), 0, s, a);
         MCG_HIP(hipGetLastError());
@@ -1600,16 +1880,16 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
 int gemm(const float* A1, int lda1, int K1, const float* A2, int lda2, int K2, const float* Bp, const float* bias,
          const float* resid, int ldr, float* C, int ldc, int M, int n_tiles, int n_store, int act, hipStream_t s,
          const uint16_t* Bp16 = nullptr, const uint16_t* Bp16x3 = nullptr, mcg_plan* side = nullptr, int rows16 = 0,
-         const int2* a2_rows = nullptr) {
+         const int4* a2_rows = nullptr, int a2_nsum = 2) {
     McgGemmArgs g{};
     g.A1 = A1; g.lda1 = lda1; g.K1 = K1; g.A2 = A2; g.lda2 = lda2; g.K2 = K2; g.Bp = Bp; g.bias = bias;
     g.resid = resid; g.ldr = ldr; g.C = C; g.ldc = ldc; g.M = M; g.n_tiles = n_tiles; g.n_store = n_store; g.act = act;
     if (side && side->x_pending && !Bp16 && !Bp16x3) {
-        g.side_u = side->Ux; g.side_slots = side->node_slots2; g.side_x = side->x; g.side_M = side->M;
+        g.side_u = side->Ux; g.side_slots = side->units().node_slots; g.side_x = side->x; g.side_M = side->M;
         side->x_pending = false;
     }
     if (rows16 > 0 && !Bp16 && !Bp16x3) {
-        g.a2_rows = a2_rows;
+        g.a2_rows = a2_rows; g.a2_nsum = a2_nsum;
         // 16-row wave tiles while they fit one wave per SIMD (972 waves at config 2), 32-row ones beyond
         const long w16 = (long)((M + 15) / 16) * ((n_tiles + rows16 - 1) / rows16);
         MCG_HIP(mcg_gemm16_launch(g, rows16, s, w16 <= 1280 ? 1 : 2));
@@ -1628,7 +1908,7 @@ int gemm(const float* A1, int lda1, int K1, const float* A2, int lda2, int K2, c
 // pending coordinate update (workgroup-level sums in pl->Ux) applied by a stand-alone launch
 int apply_pending_x(mcg_plan* pl, hipStream_t s) {
     if (!pl->x_pending) return MCG_OK;
-    hipLaunchKernelGGL(k_coord_apply2, dim3((pl->M * 4 + 255) / 256), dim3(256), 0, s, pl->Ux, pl->node_slots2, pl->M, pl->x);
+    hipLaunchKernelGGL(k_coord_apply2, dim3((pl->M * 4 + 255) / 256), dim3(256), 0, s, pl->Ux, pl->units().node_slots, pl->M, pl->x);
     MCG_HIP(hipGetLastError());
     pl->x_pending = false;
     return MCG_OK;
@@ -1650,11 +1930,11 @@ int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s, bool keep
                      MCG_ACT_NONE, s, lp ? E.pab_Bp16 : nullptr, x6g ? E.pab_Bp16x3 : nullptr, pl)) return e;
     if (int e = apply_pending_x(pl, s)) return e;              // (only if the GEMM above could not carry it)
     if (int e = run_edge(pl, E, false, pl->P, s, lp, m->x6, wgc)) return e;
-    const int2* gather = nullptr;
+    const int4* gather = nullptr;
     if (wgc && f32 && !keep_agg) {
-        gather = pl->node_slots2;                               // the node GEMM adds an atom's two rows of U itself
+        gather = pl->units().node_slots;                        // the node GEMM adds an atom's rows of U itself
     } else if (wgc) {
-        hipLaunchKernelGGL(k_gather_agg2, dim3(M), dim3(128), 0, s, pl->U, pl->node_slots2, pl->agg);
+        hipLaunchKernelGGL(k_gather_agg2, dim3(M), dim3(128), 0, s, pl->U, pl->units().node_slots, pl->agg);
         MCG_HIP(hipGetLastError());
     } else {
         // (reading the per-wave partials directly in the node GEMM's A-loader was tried: the 4-way gather costs the
@@ -1666,7 +1946,7 @@ int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s, bool keep
     // balance these two GEMMs on 1024 SIMDs at config 2 (972 waves); larger batches take 32-row tiles (gemm()).
     const int r16 = f32 ? 3 : 0;
     if (int e = gemm(pl->h, HP, H, gather ? pl->U : pl->agg, HP, H, Nl.w3_Bp, Nl.b3, nullptr, 0, pl->t1, HP, M, NT, HP, MCG_ACT_SILU, s,
-                     lp ? Nl.w3_Bp16 : nullptr, x6g ? Nl.w3_Bp16x3 : nullptr, nullptr, gather ? 3 : r16, gather)) return e;
+                     lp ? Nl.w3_Bp16 : nullptr, x6g ? Nl.w3_Bp16x3 : nullptr, nullptr, gather ? 3 : r16, gather, pl->units().max_span)) return e;
     if (int e = gemm(pl->t1, HP, H, nullptr, 0, 0, Nl.w4_Bp, Nl.b4, pl->h, HP, pl->h2, HP, M, NT, HP, MCG_ACT_NONE, s,
                      lp ? Nl.w4_Bp16 : nullptr, x6g ? Nl.w4_Bp16x3 : nullptr, nullptr, r16)) return e;
     std::swap(pl->h, pl->h2);
@@ -1878,15 +2158,15 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
             }
         }
     }
-    // workgroup-level tables (MT = 1): workgroup w = units 4w .. 4w+3 = rows [64w, 64w + 64)
-    std::vector<int> wave_ws(p->n_waves + 1, 0), wg_sbase, wg_info;
-    std::vector<int> node_slots2((size_t)(p->M > 0 ? p->M : 1) * 2, 0);
+    // workgroup-level tables (MT = 1).  A "unit" is what one workgroup of the throughput kernel processes:
+    //   unit w <  n_full : tiles 4w .. 4w+3 = rows [64w, 64w + 64), one tile per wave (the LDS-staged body)
+    //   unit w >= n_full : ONE tile, 4 * n_full + (w - n_full), its columns split over the 4 waves (the quarter-tile
+    //                      body: the last, partly filled round of the chip runs 4x more workgroups with 4x shorter chains)
+    std::vector<int> wave_ws(p->n_waves + 1, 0), unit_sbase, wg_info;
+    std::vector<int> node_slots2((size_t)(p->M > 0 ? p->M : 1) * 4, 0);
+    std::vector<int> first_node(p->n_waves, -1), last_node(p->n_waves, -1);
     bool wgc_ok = best == 1 && p->n_waves > 0;
-    if (wgc_ok) {
-        const int n_wg = (p->n_waves + 3) / 4;
-        wg_sbase.assign(n_wg + 1, 0);
-        wg_info.assign((size_t)n_wg * 4, 0);
-        std::vector<int> first_node(p->n_waves, -1), last_node(p->n_waves, -1);
+    if (wgc_ok)
         for (int b = 0; b < B; ++b) {
             const int n = nn[b];
             for (int i = 0; i < n && n > 1; ++i) {
@@ -1898,46 +2178,90 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
                 }
             }
         }
-        for (int w = 0; w < n_wg; ++w) {
+    const int n_wg_all = (p->n_waves + 3) / 4;
+    int span = 2;
+    int n_units = 0;
+    // tables for `n_full` four-tile units followed by one-tile units; false when an atom's rows would span more than
+    // `max_span` units or a four-tile unit touches more than 16 atoms
+    auto build_units = [&](int n_full, int max_span) -> bool {
+        const int n_tail = n_full < n_wg_all ? p->n_waves - 4 * n_full : 0;
+        n_units = n_full + n_tail;
+        unit_sbase.assign(n_units + 1, 0);
+        wg_info.assign((size_t)n_units * 4, 0);
+        span = 2;
+        for (int w = 0; w < n_units; ++w) {
+            const int u0 = w < n_full ? 4 * w : 4 * n_full + (w - n_full);
+            const int u1 = w < n_full ? std::min(4 * w + 4, p->n_waves) : u0 + 1;
             int slots = 0, rows = 0;                // rows: LDS rows the waves park their segment sums in (<= 16 fit)
-            for (int u = 4 * w; u < std::min(4 * w + 4, p->n_waves); ++u) {
+            int ws_pack = 0, ns_pack = 0;
+            for (int u = u0; u < u1; ++u) {
                 const int nseg = wave_poff[u + 1] - wave_poff[u];
                 rows += nseg;
-                const bool cont = u > 4 * w && nseg > 0 && first_node[u] == last_node[u - 1];
+                const bool cont = u > u0 && nseg > 0 && first_node[u] == last_node[u - 1];
                 const int ws0 = cont ? slots - 1 : slots;
-                wave_ws[u] = ws0 | ((cont ? 1 : 0) << 8);
+                wave_ws[u] = ws0;
                 slots = ws0 + nseg;
+                ws_pack |= (ws0 & 0xff) << (8 * (u - u0));
+                ns_pack |= (nseg & 0xff) << (8 * (u - u0));
             }
-            if (rows > 16) wgc_ok = false;
-            int ws_pack = 0, ns_pack = 0;
-            for (int u = 4 * w; u < std::min(4 * w + 4, p->n_waves); ++u) {
-                ws_pack |= (wave_ws[u] & 0xff) << (8 * (u - 4 * w));
-                ns_pack |= ((wave_poff[u + 1] - wave_poff[u]) & 0xff) << (8 * (u - 4 * w));
-            }
-            wg_info[4 * (size_t)w] = wg_sbase[w]; wg_info[4 * (size_t)w + 1] = slots;
+            if (rows > 16) return false;
+            wg_info[4 * (size_t)w] = unit_sbase[w]; wg_info[4 * (size_t)w + 1] = slots;
             wg_info[4 * (size_t)w + 2] = ws_pack; wg_info[4 * (size_t)w + 3] = ns_pack;
-            wg_sbase[w + 1] = wg_sbase[w] + slots;
+            unit_sbase[w + 1] = unit_sbase[w] + slots;
         }
-        p->n_uslots = wg_sbase[n_wg];
-        const int zero = p->n_uslots;
-        for (int v = 0; v < p->M; ++v) node_slots2[2 * v] = node_slots2[2 * v + 1] = zero;
-        for (int b = 0; b < B && wgc_ok; ++b) {
+        for (size_t k = 0; k < node_slots2.size(); ++k) node_slots2[k] = -1;     // unused: patched to the zero row below
+        auto unit_of = [&](int u) { return u < 4 * n_full ? u / 4 : n_full + (u - 4 * n_full); };
+        for (int b = 0; b < B; ++b) {
             const int n = nn[b];
             for (int i = 0; i < n && n > 1; ++i) {
                 const int v = node_off[b] + i;
                 const int first = row_off[b] + i * (n - 1), last = first + n - 2;
-                const int w_lo = first / 64, w_hi = last / 64;
-                if (w_hi - w_lo > 1) { wgc_ok = false; break; }
-                // slot of atom v inside workgroup w = slot of the unit holding its first row there + its segment there
-                auto slot_in = [&](int w) {
-                    const int r = std::max(first, 64 * w);
-                    const int u = r / 16;
-                    return wg_sbase[w] + (wave_ws[u] & 0xff) + (ij[2 * (size_t)r + 1] >> 24);
-                };
-                node_slots2[2 * v] = slot_in(w_lo);
-                if (w_hi > w_lo) node_slots2[2 * v + 1] = slot_in(w_hi);
+                int cnt = 0, prev = -1;
+                for (int u = first / 16; u <= last / 16; ++u) {
+                    const int w = unit_of(u);
+                    if (w == prev) continue;
+                    prev = w;
+                    if (cnt == max_span) return false;
+                    // slot of atom v inside unit w = slot base of the tile holding its first row there + its segment there
+                    const int r = std::max(first, 16 * u);
+                    node_slots2[4 * (size_t)v + cnt++] = unit_sbase[w] + wave_ws[u] + (ij[2 * (size_t)r + 1] >> 24);
+                }
+                span = std::max(span, cnt);
             }
         }
+        return true;
+    };
+    // table sets: [0] the automatic split, [1] four-tile units only (when different)
+    struct HostTables { std::vector<int> wg_info, node_slots; int n_units = 0, n_full = 0, n_uslots = 0, span = 2; };
+    HostTables ht[2];
+    int n_sets = 0;
+    auto keep = [&](int n_full) {
+        HostTables& t = ht[n_sets++];
+        t.wg_info = wg_info; t.node_slots = node_slots2; t.n_units = n_units; t.n_full = n_full;
+        t.n_uslots = unit_sbase[n_units]; t.span = span;
+    };
+    if (wgc_ok) {
+        // Only COMPLETE rounds of the chip (2 resident workgroups per CU) take the four-tile body: in a partly filled last
+        // round every SIMD would walk a whole tile's 93 k-cycle MFMA chain with part of the chip idle.  The quarter-tile
+        // body costs ~18 % more SIMD time per tile (4x the row decode / prologue / epilogue per tile), so a last round that
+        // is more than ~80 % full (r > 400 of 512 workgroups) stays with four-tile units.  Measured per edge launch
+        // (tools/tail_sweep.sh, 27-atom molecules): 702 workgroups 156.9 -> 148.3 us, 1053: 242.6 -> 209.4 us,
+        // 351: 101.0 -> 88.7 us, 44: 55.8 -> 17.5 us.
+        // MCG_TAIL=0 disables the quarter-tile units, MCG_TAIL=n forces n four-tile units, -1 none (measurement).
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipGetLastError();
+        const int round = 2 * (cus > 0 ? cus : 256);
+        const int r = n_wg_all % round;
+        int n_full = r * 512 <= 400 * round ? n_wg_all - r : n_wg_all;
+        if (const char* e = getenv("MCG_TAIL")) {
+            const int t = atoi(e);
+            n_full = t == 0 ? n_wg_all : t < 0 ? 0 : std::min(((t + 7) / 8) * 8, n_wg_all);
+        }
+        if (n_full < n_wg_all && build_units(n_full, 4)) keep(n_full);
+        wgc_ok = build_units(n_wg_all, 2);
+        if (wgc_ok) keep(n_wg_all);
+        else if (n_sets > 0) wgc_ok = true;         // (four-tile units alone would touch > 16 atoms: tiny molecules)
     }
     p->wgc = wgc_ok;
     if (!segs_ok) {
@@ -1963,14 +2287,20 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
     e |= upload_i(nn, &p->n_nodes); e |= upload_i(node_off, &p->node_off); e |= upload_i(row_off, &p->row_off);
     e |= upload_i(tile_mol, &p->tile_mol); e |= upload_i(wave_poff, &p->wave_poff);
     e |= upload_i(node_mol, &p->node_mol);
-    if (p->wgc) {
+    int max_uslots = 0;
+    for (int k = 0; k < n_sets; ++k) max_uslots = std::max(max_uslots, ht[k].n_uslots);
+    for (int k = 0; k < n_sets; ++k) {
+        for (int& v : ht[k].node_slots) if (v < 0) v = max_uslots;       // the zero row (never written) is common to both sets
         int* d = nullptr;
         int* wi = nullptr;
-        e |= upload_i(wg_info, &wi); e |= upload_i(node_slots2, &d);
-        p->wg_info = reinterpret_cast<int4*>(wi);
-        p->node_slots2 = reinterpret_cast<int2*>(d);
+        e |= upload_i(ht[k].wg_info, &wi); e |= upload_i(ht[k].node_slots, &d);
+        mcg_plan::UnitTables& T = p->ut[k];
+        T.wg_info = reinterpret_cast<int4*>(wi);
+        T.node_slots = reinterpret_cast<int4*>(d);
+        T.n_units = ht[k].n_units; T.n_full_wg = ht[k].n_full; T.n_uslots = ht[k].n_uslots; T.max_span = ht[k].span;
         p->allocs.insert(p->allocs.end(), {(void*)wi, (void*)d});
     }
+    p->have_alt = n_sets == 2;
     if (e) { mcg_plan_destroy(p); return MCG_ERR_HIP; }
     p->allocs.insert(p->allocs.end(), {(void*)p->n_nodes, (void*)p->node_off, (void*)p->row_off, (void*)p->tile_mol,
                                        (void*)p->wave_poff, (void*)p->node_mol});
@@ -1979,7 +2309,7 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
         // (+64 floats: the bf16 kernels read activation rows up to k = 447, i.e. 16 floats past the last row)
         {&p->x, M1 * 4}, {&p->x0, M1 * 4}, {&p->h, M1 * HP + 64}, {&p->h2, M1 * HP + 64}, {&p->pab, M1 * 2 * HP + 64},
         {&p->agg, M1 * HP + 64}, {&p->t1, M1 * HP + 64}, {&p->P, (size_t)(p->n_pslots + 1) * HP}, {&p->Px, (size_t)(p->n_pslots + 1) * 4},
-        {&p->U, (size_t)(p->n_uslots + 1) * HP + 64}, {&p->Ux, (size_t)(p->n_uslots + 1) * 4}};
+        {&p->U, (size_t)(max_uslots + 1) * HP + 64}, {&p->Ux, (size_t)(max_uslots + 1) * 4}};
     for (auto& b : bufs) {
         if (hipMalloc((void**)b.ptr, b.n * sizeof(float)) != hipSuccess || hipMemset(*b.ptr, 0, b.n * sizeof(float)) != hipSuccess) {
             mcg_set_error("mcg_plan_create: out of device memory (%zu floats)", b.n);
@@ -2064,7 +2394,7 @@ static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, i
     return MCG_OK;
 }
 
-// mode: -1 auto (column-split latency kernel for <= 512 edge tiles), 0 never, 1 always
+// mode: -1 auto, 0 four-tile units only, 1 the stand-alone column-split kernel
 int mcg_plan_set_latency_mode(mcg_plan* p, int mode) {
     if (!p || mode < -1 || mode > 1) return MCG_ERR_ARG;
     p->latency_mode = mode;
@@ -2106,7 +2436,7 @@ static int dynamics_launch(const mcg_egnn* m, mcg_plan* pl, const float* t, cons
     // (the last block's coordinate update is folded into the output head)
     hipLaunchKernelGGL(k_output, dim3(pl->B), dim3(512), 0, s, pl->h, pl->x, pl->x0, pl->n_nodes, pl->node_off, pl->N,
                        m->out_w, m->out_b, out, pl->x_pending ? pl->Ux : (const float*)nullptr,
-                       pl->x_pending ? pl->node_slots2 : (const int2*)nullptr);
+                       pl->x_pending ? pl->units().node_slots : (const int4*)nullptr);
     MCG_HIP(hipGetLastError());
     pl->x_pending = false;
     return MCG_OK;

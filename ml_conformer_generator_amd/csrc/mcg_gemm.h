@@ -39,22 +39,23 @@ struct McgGemmArgs {
     int M; int n_tiles; int n_store;        // columns >= n_store are not written
     int act;
     // --- mcg_gemm16_kernel only (value-initialise the struct: zero = unused) ---
-    const int2* a2_rows;                    // optional: row r of segment 2 is the SUM of rows a2_rows[r].x and .y of A2
-                                            // (the two workgroup-level partial-sum slots of a node, mcg_egnn.hip)
+    const int4* a2_rows;                    // optional: row r of segment 2 is the SUM of the first a2_nsum (2..4) of rows
+    int a2_nsum;                            // a2_rows[r].x .y .z .w of A2: the workgroup-level partial-sum slots of an atom (mcg_egnn.hip)
     // side job run by the blocks beyond the GEMM's own grid (independent data, saves a launch):
-    // x[v][0..2] += (side_u[s.x] + side_u[s.y]) / 100 - the coordinate update of the previous block (egnn.py:128-148)
-    const float* side_u; const int2* side_slots; float* side_x; int side_M;
+    // x[v][0..2] += (side_u[s.x] + side_u[s.y] + side_u[s.z] + side_u[s.w]) / 100 - the coordinate update of the previous block (egnn.py:128-148)
+    const float* side_u; const int4* side_slots; float* side_x; int side_M;
     int gemm_blocks;                        // workgroups of the GEMM proper (set by the launcher)
 };
 
 // Side job of the fp32 node GEMM launches (workgroups beyond the GEMM's own grid): the coordinate update of the
-// previous EquivariantBlock, x[v] += (u[s.x] + u[s.y]) / 100 (egnn.py:128-148) - independent data, saves a launch.
+// previous EquivariantBlock, x[v] += (u[s.x] + u[s.y] + u[s.z] + u[s.w]) / 100 (egnn.py:128-148) - independent data, saves a launch.
 __device__ __forceinline__ void mcg_gemm_side_job(const McgGemmArgs& p, int block) {
     const int idx = block * 256 + (int)threadIdx.x;
     const int v = idx >> 2, comp = idx & 3;
     if (v < p.side_M && comp < 3) {
-        const int2 sl = p.side_slots[v];
-        p.side_x[(size_t)v * 4 + comp] += (p.side_u[(size_t)sl.x * 4 + comp] + p.side_u[(size_t)sl.y * 4 + comp]) / 100.0f;
+        const int4 sl = p.side_slots[v];
+        p.side_x[(size_t)v * 4 + comp] += (((p.side_u[(size_t)sl.x * 4 + comp] + p.side_u[(size_t)sl.y * 4 + comp]) + p.side_u[(size_t)sl.z * 4 + comp]) +
+                                           p.side_u[(size_t)sl.w * 4 + comp]) / 100.0f;
     }
 }
 
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(256) void mcg_gemm_kernel(McgGemmArgs p) {
 // N = 432: 756 waves of 840 MFMAs = 11.2 us of serial chain on 74 % of the SIMDs); 16 x 3 tiles give 972 waves
 // of 630 MFMAs (8.4 us), 16 x 6 the same for N = 864.  Same operand packs, ring discipline and transposed
 // accumulators as mcg_gemm_kernel.  GATHER: segment-2 rows are read as the sum of two rows (see a2_rows).
-template <int RN, bool GATHER, int MR = 1, int RING = 3>      // MR row tiles of 16 per wave (1: 16-row wave tiles, 2: 32-row)
+template <int RN, int GATHER, int MR = 1, int RING = 3>       // GATHER 0 / 2 / 3 / 4 rows summed per A2 row; MR row tiles of 16 per wave
 __global__ __launch_bounds__(256) void mcg_gemm16_kernel(McgGemmArgs p) {
     if ((int)blockIdx.x >= p.gemm_blocks) { mcg_gemm_side_job(p, (int)blockIdx.x - p.gemm_blocks); return; }
     const int lane = threadIdx.x & 63;
@@ -650,18 +651,23 @@ __global__ __launch_bounds__(256) void mcg_gemm16_kernel(McgGemmArgs p) {
                                                                             : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const float* bseg = p.Bp;
-    // one K segment; TWO: activation rows are the sum of two rows (row indices ra[m], rb[m])
-    auto segment = [&](auto two_tag, const float* A, int K, int lda, const int (&ra)[MR], const int (&rb)[MR]) {
-        constexpr bool TWO = decltype(two_tag)::value;
+    // one K segment; NSUM = 1: plain rows ra; 2 / 3 / 4: activation rows are the sum of rows ra, rb (, rc (, rd))
+    auto segment = [&](auto nsum_tag, const float* A, int K, int lda, const int (&ra)[MR], const int (&rb)[MR], const int (&rc)[MR],
+                       const int (&rd)[MR]) {
+        constexpr int NSUM = decltype(nsum_tag)::value;
+        constexpr bool TWO = NSUM >= 2, THREE = NSUM >= 3, FOUR = NSUM >= 4;
         const int groups = K / 16;
         const size_t gstride = (size_t)p.n_tiles * 256;
         if (groups > 0) {
-            f32x4 Ar[RING][MR], Ar2[RING][MR], Br[RING][RN];
+            f32x4 Ar[RING][MR], Ar2[RING][MR], Ar3[RING][MR], Ar4[RING][MR], Br[RING][RN];
             const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, 0xffffffff, 0x00020000);
             const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bseg), 0, 0xffffffff, 0x00020000);
-            unsigned oa[MR], oa2[MR];
+            unsigned oa[MR], oa2[MR], oa3[MR], oa4[MR];
 #pragma unroll
-            for (int m = 0; m < MR; ++m) { oa[m] = (unsigned)(ra[m] * lda + 4 * g) * 4u; oa2[m] = (unsigned)(rb[m] * lda + 4 * g) * 4u; }
+            for (int m = 0; m < MR; ++m) {
+                oa[m] = (unsigned)(ra[m] * lda + 4 * g) * 4u; oa2[m] = (unsigned)(rb[m] * lda + 4 * g) * 4u; oa3[m] = (unsigned)(rc[m] * lda + 4 * g) * 4u;
+                oa4[m] = (unsigned)(rd[m] * lda + 4 * g) * 4u;
+            }
             unsigned obn[RN];
 #pragma unroll
             for (int n = 0; n < RN; ++n) obn[n] = (unsigned)((nt0 + ncl[n]) * 256 + lane * 4) * 4u;
@@ -672,6 +678,8 @@ __global__ __launch_bounds__(256) void mcg_gemm16_kernel(McgGemmArgs p) {
                 for (int m = 0; m < MR; ++m) {
                     Ar[slot][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)oa[m], 64 * q, 0));
                     if (TWO) Ar2[slot][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)oa2[m], 64 * q, 0));
+                    if (THREE) Ar3[slot][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)oa3[m], 64 * q, 0));
+                    if (FOUR) Ar4[slot][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)oa4[m], 64 * q, 0));
                 }
 #pragma unroll
                 for (int n = 0; n < RN; ++n)
@@ -680,7 +688,9 @@ __global__ __launch_bounds__(256) void mcg_gemm16_kernel(McgGemmArgs p) {
             auto compute = [&](int slot) {
                 f32x4 a[MR];
 #pragma unroll
-                for (int m = 0; m < MR; ++m) a[m] = TWO ? Ar[slot][m] + Ar2[slot][m] : Ar[slot][m];
+                for (int m = 0; m < MR; ++m)
+                    a[m] = FOUR ? ((Ar[slot][m] + Ar2[slot][m]) + Ar3[slot][m]) + Ar4[slot][m]
+                         : THREE ? (Ar[slot][m] + Ar2[slot][m]) + Ar3[slot][m] : TWO ? Ar[slot][m] + Ar2[slot][m] : Ar[slot][m];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -711,6 +721,8 @@ __global__ __launch_bounds__(256) void mcg_gemm16_kernel(McgGemmArgs p) {
             for (int m = 0; m < MR; ++m) {
                 av[m] = A[(size_t)ra[m] * lda + k];
                 if (TWO) av[m] += A[(size_t)rb[m] * lda + k];
+                if (THREE) av[m] += A[(size_t)rc[m] * lda + k];
+                if (FOUR) av[m] += A[(size_t)rd[m] * lda + k];
             }
 #pragma unroll
             for (int n = 0; n < RN; ++n) {
@@ -721,15 +733,15 @@ __global__ __launch_bounds__(256) void mcg_gemm16_kernel(McgGemmArgs p) {
         }
         bseg += mcg_pack4_floats(K, p.n_tiles);
     };
-    if (p.K1 > 0) segment(std::false_type{}, p.A1, p.K1, p.lda1, rA, rA);
+    if (p.K1 > 0) segment(std::integral_constant<int, 1>{}, p.A1, p.K1, p.lda1, rA, rA, rA, rA);
     if (p.K2 > 0) {
         if (GATHER) {
-            int sa[MR], sb[MR];
+            int sa[MR], sb[MR], sc[MR], sd[MR];
 #pragma unroll
-            for (int m = 0; m < MR; ++m) { const int2 sl = p.a2_rows[rA[m]]; sa[m] = sl.x; sb[m] = sl.y; }
-            segment(std::true_type{}, p.A2, p.K2, p.lda2, sa, sb);
+            for (int m = 0; m < MR; ++m) { const int4 sl = p.a2_rows[rA[m]]; sa[m] = sl.x; sb[m] = sl.y; sc[m] = sl.z; sd[m] = sl.w; }
+            segment(std::integral_constant<int, (GATHER >= 2 ? GATHER : 1)>{}, p.A2, p.K2, p.lda2, sa, sb, sc, sd);
         } else {
-            segment(std::false_type{}, p.A2, p.K2, p.lda2, rA, rA);
+            segment(std::integral_constant<int, 1>{}, p.A2, p.K2, p.lda2, rA, rA, rA, rA);
         }
     }
 #pragma unroll
@@ -769,14 +781,15 @@ static inline hipError_t mcg_gemm16_launch(McgGemmArgs a, int rn, hipStream_t s,
     a.gemm_blocks = (int)((waves + 3) / 4);
     const int side = a.side_x ? (a.side_M * 4 + 255) / 256 : 0;
     const dim3 grid((unsigned)(a.gemm_blocks + side));
-    const bool gather = a.a2_rows != nullptr && a.K2 > 0;
-#define MCG_G16(RN_, G_, MR_) hipLaunchKernelGGL((mcg_gemm16_kernel<RN_, G_, MR_>), grid, dim3(256), 0, s, a)
-    if (mr == 2) {
-        if (rn == 3) { if (gather) MCG_G16(3, true, 2); else MCG_G16(3, false, 2); }
-        else { if (gather) MCG_G16(2, true, 2); else MCG_G16(2, false, 2); }
-    } else if (rn == 6) { if (gather) MCG_G16(6, true, 1); else MCG_G16(6, false, 1); }
-    else if (rn == 3) { if (gather) MCG_G16(3, true, 1); else MCG_G16(3, false, 1); }
-    else { if (gather) MCG_G16(2, true, 1); else MCG_G16(2, false, 1); }
+    const int gather = (a.a2_rows != nullptr && a.K2 > 0) ? (a.a2_nsum >= 4 ? 4 : a.a2_nsum == 3 ? 3 : 2) : 0;
+#define MCG_G16(RN_, MR_) do { if (gather == 4) hipLaunchKernelGGL((mcg_gemm16_kernel<RN_, 4, MR_>), grid, dim3(256), 0, s, a); \
+                               else if (gather == 3) hipLaunchKernelGGL((mcg_gemm16_kernel<RN_, 3, MR_>), grid, dim3(256), 0, s, a); \
+                               else if (gather == 2) hipLaunchKernelGGL((mcg_gemm16_kernel<RN_, 2, MR_>), grid, dim3(256), 0, s, a); \
+                               else hipLaunchKernelGGL((mcg_gemm16_kernel<RN_, 0, MR_>), grid, dim3(256), 0, s, a); } while (0)
+    if (mr == 2) { if (rn == 3) MCG_G16(3, 2); else MCG_G16(2, 2); }
+    else if (rn == 6) MCG_G16(6, 1);
+    else if (rn == 3) MCG_G16(3, 1);
+    else MCG_G16(2, 1);
 #undef MCG_G16
     return hipGetLastError();
 }

@@ -106,7 +106,7 @@ def test_gcl_internals_vs_oracle(dyn, edm_sd):
     w1, b1 = edm_sd[p + "edge_mlp.0.weight"], edm_sd[p + "edge_mlp.0.bias"]
     pab_ref = torch.cat([F.linear(g["h_in"], w1[:, :420], b1), F.linear(g["h_in"], w1[:, 420:840])], 1)
     hid_ref = F.silu(F.linear(torch.cat([g["h_in"], agg_ref], 1), edm_sd[p + "node_mlp.0.weight"], edm_sd[p + "node_mlp.0.bias"]))
-    for mode in (0, 1):                               # throughput and column-split edge kernels
+    for mode in (-1, 0, 1):                           # quarter-tile units (auto at this size), four-tile units, k_edge_ns
         plan = dyn.plan(nm.sum(1).reshape(-1).to(torch.int32), N, edge_mt=1)
         plan.set_latency_mode(mode)
         got = dyn.gcl_debug(plan, 6, g["h_in"][real], g["x_in"][real], g["x0"][real])
@@ -135,7 +135,7 @@ def test_tiny_molecules_fill_tiles_with_many_segments(dyn, edm_sd, sizes):
     ctx = torch.randn(B, 1, 3).repeat(1, N, 1) * nm
     t = torch.full((B, 1), 0.4)
     ref = EO.egnn_dynamics(edm_sd, t, z, nm, em, ctx)
-    for mode in (0, 1):
+    for mode in (-1, 0, 1):
         plan = dyn.plan(sz, N, edge_mt=1)
         plan.set_latency_mode(mode)
         out = dyn.run(plan, t.reshape(-1).to(DEV), z.to(DEV), ctx.to(DEV))
@@ -163,8 +163,8 @@ def test_dynamics_seam_vs_golden(dyn, tag):
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("tag", ["b2n20", "b3n39", "b3n27_x30"])
 def test_both_edge_kernels_on_the_golden_shapes(dyn, tag, mode):
-    """The throughput kernel (mode 0) and the column-split latency kernel (mode 1) on the same small golden
-    inputs (auto mode would only pick the latency kernel at these sizes)."""
+    """Four-tile workgroups only (mode 0) and the stand-alone column-split kernel (mode 1) on the same small golden
+    inputs (auto mode runs these sizes on the quarter-tile units of the throughput kernel: test_dynamics_seam_vs_golden)."""
     g = load_golden(f"dynamics_{tag}.npz")
     nm = g["node_mask"]
     B, N, _ = nm.shape
@@ -174,6 +174,30 @@ def test_both_edge_kernels_on_the_golden_shapes(dyn, tag, mode):
     plan.set_latency_mode(-1)
     ok, err, sc = close(out, g["out"])
     assert ok, f"mode {mode}: err {err} scale {sc}"
+
+
+@pytest.mark.parametrize("tail", ["-1", "0", "16", "40"])
+def test_mixed_four_tile_and_quarter_tile_units_vs_oracle(dyn, edm_sd, tail, monkeypatch):
+    """One edge launch whose first workgroups take four tiles and whose last take one tile each (MCG_TAIL is read at
+    plan creation): ragged molecules, so atoms straddle two four-tile units, a four-tile and a quarter-tile unit, or
+    three quarter-tile units (the node GEMM's three-row gather)."""
+    from oracle import egnn_oracle as EO
+    from oracle import host_oracle as HO
+    torch.manual_seed(23)
+    sz = torch.randint(12, 41, (10,))
+    sz[3] = 40
+    B, N = sz.numel(), 40
+    nm, em = HO.masks_from_sizes(sz, N)
+    z = torch.randn(B, N, 11) * nm
+    ctx = torch.randn(B, 1, 3).repeat(1, N, 1) * nm
+    t = torch.full((B, 1), 0.6)
+    ref = EO.egnn_dynamics(edm_sd, t, z, nm, em, ctx)
+    monkeypatch.setenv("MCG_TAIL", tail)
+    plan = dyn.plan(sz, N, edge_mt=1)
+    out = dyn.run(plan, t.reshape(-1).to(DEV), z.to(DEV), ctx.to(DEV))
+    ok, err, sc = close(out, ref)
+    assert ok, f"MCG_TAIL={tail}: err {err} scale {sc}"
+    assert float((out.cpu() * (1 - nm)).abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("mt", [1, 2])

@@ -12,12 +12,16 @@ ap.add_argument("--shape", default="c2")
 ap.add_argument("--mt", type=int, default=0)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--dtype", default="f32")
+ap.add_argument("--mols", type=int, default=0, help="override: this many molecules of --atoms atoms")
+ap.add_argument("--atoms", type=int, default=27)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 dyn = EGNNDynamics(device=dev)
 dyn.load_reference_state_dict(W.synth_edm_state_dict(1234))
 dyn.set_precision(a.dtype)
-if a.shape == "c2":
+if a.mols > 0:
+    sizes = torch.full((a.mols,), a.atoms, dtype=torch.int32); N = a.atoms
+elif a.shape == "c2":
     sizes = torch.full((64,), 27, dtype=torch.int32); N = 27
 else:
     torch.manual_seed(7); sizes = torch.randint(15, 40, (256,)).to(torch.int32); N = 39

@@ -77,16 +77,16 @@ int main(int argc, char** argv) {
     }
     // 16-row wave tiles (mcg_gemm16_kernel): RN = 2 / 3 / 6, and the two-slot gather form of the W3 GEMM
     {
-        std::vector<int> sl(2 * (size_t)M);
-        for (int v = 0; v < M; ++v) { sl[2 * v] = v; sl[2 * v + 1] = (v * 7 + 3) % M; }
-        int2* slots; hipMalloc(&slots, sl.size() * 4); hipMemcpy(slots, sl.data(), sl.size() * 4, hipMemcpyHostToDevice);
+        std::vector<int> sl(4 * (size_t)M);
+        for (int v = 0; v < M; ++v) { sl[4 * v] = v; sl[4 * v + 1] = (v * 7 + 3) % M; sl[4 * v + 2] = (v * 5 + 1) % M; sl[4 * v + 3] = (v * 3 + 2) % M; }
+        int4* slots; hipMalloc(&slots, sl.size() * 4); hipMemcpy(slots, sl.data(), sl.size() * 4, hipMemcpyHostToDevice);
         for (int which = 0; which < 3; ++which)
-            for (int gather = 0; gather <= (which == 1 ? 1 : 0); ++gather)
+            for (int gather = 0; gather <= (which == 1 ? 4 : 0); gather += (gather ? 1 : 2))
                 for (int rn : {2, 3}) {
                     auto run = [&](int n) {
                         for (int i = 0; i < n; ++i) {
                             McgGemmArgs g = args(which, i % SETS);
-                            if (gather) g.a2_rows = slots;
+                            if (gather) { g.a2_rows = slots; g.a2_nsum = gather; }
                             mcg_gemm16_launch(g, rn, s, MR16);
                         }
                     };
@@ -97,7 +97,7 @@ int main(int argc, char** argv) {
                     hipEventRecord(e1, s);
                     hipStreamSynchronize(s);
                     float ms; hipEventElapsedTime(&ms, e0, e1);
-                    printf("M=%d %d-row %-26s RN=%d%s  %.1f us  %.1f TFLOP/s\n", M, 16 * MR16, names[which], rn, gather ? " gather2" : "", ms * 1e3 / iters,
+                    printf("M=%d %d-row %-26s RN=%d%s  %.1f us  %.1f TFLOP/s\n", M, 16 * MR16, names[which], rn, gather == 4 ? " gather4" : gather == 3 ? " gather3" : gather ? " gather2" : "", ms * 1e3 / iters,
                            flops[which] / (ms * 1e-3 / iters) / 1e12);
                 }
     }
