@@ -408,15 +408,8 @@ __device__ __forceinline__ void edge_quarter_body(const EdgeArgs& p, int unit, i
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
-#ifdef MCG_QX_STAMP
-    unsigned long long ts[6];
-    ts[0] = __builtin_amdgcn_s_memtime();
-#endif
     RowInfo<1> R;
     edge_decode_ij<1>(p, tile, true, c, R);
-#ifdef MCG_QX_STAMP
-    { int dummy = __builtin_amdgcn_readfirstlane(R.ni[0]); asm volatile("" :: "s"(dummy)); ts[1] = __builtin_amdgcn_s_memtime(); }
-#endif
     const int4 wi = p.wg_info[unit];
     const int sbase = __builtin_amdgcn_readfirstlane(wi.x), nseg = __builtin_amdgcn_readfirstlane(wi.y);
     float* abuf = lds;
@@ -483,9 +476,6 @@ __device__ __forceinline__ void edge_quarter_body(const EdgeArgs& p, int unit, i
     if (wid < 3) a_publish(ain, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
-#ifdef MCG_QX_STAMP
-    ts[2] = __builtin_amdgcn_s_memtime();
-#endif
 
     // one super-group = groups 3 SG .. 3 SG + 2.  MODE 0: regular (refill the ring with groups 3 SG + 3 ..),
     // 1: SG = 7 (the refill of slot 2 is the tail k-step), 2: SG = 8 (groups 24, 25 and the tail k-step; no refill)
@@ -494,12 +484,10 @@ __device__ __forceinline__ void edge_quarter_body(const EdgeArgs& p, int unit, i
         f32x4 Aq[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) Aq[j] = *reinterpret_cast<const f32x4*>(abuf + (((SG & 1) * 3 + j) * 64 + lane) * 4);
-#ifndef MCG_QX_NOAGEN
         if (MODE < 2 && wid < 3) {
             if (MODE == 1 && wid == 2) a_load_tail(ain);
             else a_load(3 * (SG + 1) + wid, ain);
         }
-#endif
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const bool tail_step = MODE == 2 && j == 2;
@@ -509,7 +497,6 @@ __device__ __forceinline__ void edge_quarter_body(const EdgeArgs& p, int unit, i
 #pragma unroll
                 for (int i = 0; i < QT; ++i) {
                     acc[i] = mcg_mfma(Aq[j][s], Bq[j][i][s], acc[i]);
-#ifndef MCG_QX_NOB
                     if (s == 3 && MODE < 2) {
                         // the fragment is consumed: refill it three groups ahead, right behind its last MFMA
                         if (MODE == 1 && j == 2) loadB_tail(Bq[j], i);
@@ -517,28 +504,20 @@ __device__ __forceinline__ void edge_quarter_body(const EdgeArgs& p, int unit, i
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                     }
-#endif
                 }
                 if (s < 3 || MODE == 2) __builtin_amdgcn_sched_group_barrier(0x008, QT, 0);
             }
-#ifndef MCG_QX_NOAGEN
             if (j == 0 && MODE < 2 && wid < 3) a_publish(ain, (SG + 1) & 1);
-#endif
         }
-#ifndef MCG_QX_NOBAR
         if (MODE < 2) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");
         }
-#endif
     };
 #pragma unroll 1
     for (int SG = 0; SG < 7; ++SG) super(std::integral_constant<int, 0>{}, SG);
     super(std::integral_constant<int, 1>{}, 7);
     super(std::integral_constant<int, 2>{}, 8);
-#ifdef MCG_QX_STAMP
-    { float dummy = acc[0][0]; asm volatile("" :: "v"(dummy)); ts[3] = __builtin_amdgcn_s_memtime(); }
-#endif
 
     // ---- epilogue on the wave's own column tiles
     float part[4] = {0.f, 0.f, 0.f, 0.f};
@@ -556,9 +535,6 @@ __device__ __forceinline__ void edge_quarter_body(const EdgeArgs& p, int unit, i
         if (c == 0) xchg[wid * 16 + 4 * g + r] = part[r];
     }
     __syncthreads();
-#ifdef MCG_QX_STAMP
-    ts[4] = __builtin_amdgcn_s_memtime();
-#endif
     float dot[4];
     int rseg[4];
 #pragma unroll
@@ -616,13 +592,6 @@ __device__ __forceinline__ void edge_quarter_body(const EdgeArgs& p, int unit, i
                 if (i < n_own) row[i * 16] = mcg_div100(acc[i][r]);
         }
     }
-#ifdef MCG_QX_STAMP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ts[5] = __builtin_amdgcn_s_memtime();
-    if (lane == 0 && (unit % 97) == 3 && p.n_rows == MCG_QX_STAMP)
-        printf("unit %d wave %d: decode %llu prologue %llu loop %llu dot+barrier %llu rest %llu total %llu\n", unit, wid,
-               ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4], ts[5] - ts[0]);
-#endif
 }
 
 // ---- throughput kernel: 4 waves per workgroup share the packed W2 through LDS -------------------
