@@ -66,6 +66,22 @@ __device__ __forceinline__ float mcg_sigmoid(float x) {
 }
 __device__ __forceinline__ float mcg_silu(float x) { return x * mcg_sigmoid(x); }
 
+// SiLU of two values with the full-rate steps as PACKED fp32 instructions (v_pk_mul_f32 / v_pk_add_f32: two lanes'
+// worth of IEEE fp32 per issue slot); the two transcendentals stay scalar.  Bit-identical to mcg_silu per element in the
+// default MCG_PRECISE mode (the same multiply by -log2(e), v_exp_f32, add, v_rcp_f32, multiply).  Every VALU
+// instruction of the edge kernel runs beside a saturated matrix pipe (no co-issue on gfx950): halving the plain ones
+// is worth ~8 cycles per SiLU.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 mcg_silu2(f32x2 x) {
+#if MCG_PRECISE != 0
+    return (f32x2){mcg_silu(x[0]), mcg_silu(x[1])};
+#else
+    const f32x2 t = x * (f32x2){-1.44269504088896340736f, -1.44269504088896340736f};
+    const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + (f32x2){1.0f, 1.0f};
+    return x * (f32x2){__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+#endif
+}
+
 __device__ __forceinline__ f32x4 mcg_mfma(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

@@ -147,6 +147,21 @@ __device__ __forceinline__ void edge_decode(const EdgeArgs& p, int wave, bool li
     edge_decode_x<MT, EQUIV>(p, R);
 }
 
+// layer-1 finish of 4 consecutive k of one edge row: SiLU(Pa_i + Pb_j + w_d d2 + w_d0 d0^2) (egnn.py:21-27 with the
+// factorised first Linear), in packed fp32 pairs
+__device__ __forceinline__ f32x4 edge_agen4(const f32x4& va, const f32x4& vb, const f32x4& wdv, const f32x4& w0v, float d2, float d02) {
+    const f32x2 dd = {d2, d2}, d0 = {d02, d02};
+    f32x2 lo = (f32x2){va[0], va[1]} + (f32x2){vb[0], vb[1]};
+    f32x2 hi = (f32x2){va[2], va[3]} + (f32x2){vb[2], vb[3]};
+    lo = __builtin_elementwise_fma((f32x2){wdv[0], wdv[1]}, dd, lo);
+    hi = __builtin_elementwise_fma((f32x2){wdv[2], wdv[3]}, dd, hi);
+    lo = __builtin_elementwise_fma((f32x2){w0v[0], w0v[1]}, d0, lo);
+    hi = __builtin_elementwise_fma((f32x2){w0v[2], w0v[3]}, d0, hi);
+    lo = mcg_silu2(lo);
+    hi = mcg_silu2(hi);
+    return (f32x4){lo[0], lo[1], hi[0], hi[1]};
+}
+
 // Epilogue shared by both edge kernels.  C/D layout: column = 16*nt + c, row = 4*g + r of tile mt.
 template <int MT, bool EQUIV>
 __device__ __forceinline__ void edge_epilogue(const EdgeArgs& p, int wave, bool live, int lane, f32x4 (&acc)[MT][NT],
@@ -266,18 +281,19 @@ __device__ __forceinline__ void edge_epilogue_wg(const EdgeArgs& p, const WgSums
                                                  f32x4 (&acc)[1][NT], const RowInfo<1>& R, const float* b2p, const float* wvp,
                                                  float* sl) {
     const int g = lane >> 4, c = lane & 15;
-    float part[4] = {0.f, 0.f, 0.f, 0.f};
     (void)b2p;                                                  // (the bias already sits in the accumulators: they start from it)
+    f32x2 part01 = {0.f, 0.f}, part23 = {0.f, 0.f};
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const float wv = wvp[nt * 16 + c];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float m = mcg_silu(acc[0][nt][r]);           // second Linear (+ bias, see k_edge_lds) + SiLU (egnn.py:26-27)
-            acc[0][nt][r] = m;
-            part[r] = fmaf(wv, m, part[r]);
-        }
+        // second Linear (+ bias, see k_edge_lds) + SiLU (egnn.py:26-27), two rows per packed instruction
+        const f32x2 m01 = mcg_silu2((f32x2){acc[0][nt][0], acc[0][nt][1]});
+        const f32x2 m23 = mcg_silu2((f32x2){acc[0][nt][2], acc[0][nt][3]});
+        acc[0][nt] = (f32x4){m01[0], m01[1], m23[0], m23[1]};
+        part01 = __builtin_elementwise_fma(m01, (f32x2){wv, wv}, part01);
+        part23 = __builtin_elementwise_fma(m23, (f32x2){wv, wv}, part23);
     }
+    const float part[4] = {part01[0], part01[1], part23[0], part23[1]};
     int rseg[4];
     float dot[4];
 #pragma unroll
@@ -440,10 +456,7 @@ __device__ __forceinline__ void edge_quarter_body(const EdgeArgs& p, int unit, i
     };
     auto a_publish = [&](AIn& in, int buf) {
         asm volatile("" : "+v"(in.va), "+v"(in.vb), "+v"(in.wdv), "+v"(in.w0v));      // (keeps the arithmetic HERE, not behind the loads)
-        f32x4 a;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) a[s] = mcg_silu(fmaf(in.w0v[s], R.d02[0], fmaf(in.wdv[s], R.d2[0], in.va[s] + in.vb[s])));
-        *reinterpret_cast<f32x4*>(abuf + ((buf * 3 + wid) * 64 + lane) * 4) = a;
+        *reinterpret_cast<f32x4*>(abuf + ((buf * 3 + wid) * 64 + lane) * 4) = edge_agen4(in.va, in.vb, in.wdv, in.w0v, R.d2[0], R.d02[0]);
     };
     // Load order = the order the prologue needs the data in (the vector-memory counter retires in order): the first
     // super-group's A inputs and the coordinates right behind the row decode, then the per-column parameters, then the
@@ -520,15 +533,17 @@ __device__ __forceinline__ void edge_quarter_body(const EdgeArgs& p, int unit, i
     super(std::integral_constant<int, 2>{}, 8);
 
     // ---- epilogue on the wave's own column tiles
-    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x2 part01 = {0.f, 0.f}, part23 = {0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < QT; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float m = mcg_silu(acc[i][r]);                    // second Linear (+ bias) + SiLU (egnn.py:26-27)
-            acc[i][r] = m;
-            part[r] = fmaf(wvr[i], m, part[r]);
-        }
+    for (int i = 0; i < QT; ++i) {
+        // second Linear (+ bias) + SiLU (egnn.py:26-27), two rows per packed instruction
+        const f32x2 m01 = mcg_silu2((f32x2){acc[i][0], acc[i][1]});
+        const f32x2 m23 = mcg_silu2((f32x2){acc[i][2], acc[i][3]});
+        acc[i] = (f32x4){m01[0], m01[1], m23[0], m23[1]};
+        part01 = __builtin_elementwise_fma(m01, (f32x2){wvr[i], wvr[i]}, part01);
+        part23 = __builtin_elementwise_fma(m23, (f32x2){wvr[i], wvr[i]}, part23);
+    }
+    float part[4] = {part01[0], part01[1], part23[0], part23[1]};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         part[r] = mcg_row16_sum(part[r]);
@@ -684,10 +699,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
     };
     auto agen = [&](const f32x4 (&va)[MT], const f32x4 (&vb)[MT], const f32x4& wdv, const f32x4& w0v, f32x4 (&a4)[MT]) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                a4[mt][s] = mcg_silu(fmaf(w0v[s], R.d02[mt], fmaf(wdv[s], R.d2[mt], va[mt][s] + vb[mt][s])));
+        for (int mt = 0; mt < MT; ++mt) a4[mt] = edge_agen4(va[mt], vb[mt], wdv, w0v, R.d2[mt], R.d02[mt]);
     };
 
     // prologue: B group 0 in flight, A operand of group 0 generated

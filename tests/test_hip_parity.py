@@ -184,8 +184,8 @@ def test_mixed_four_tile_and_quarter_tile_units_vs_oracle(dyn, edm_sd, tail, mon
     from oracle import egnn_oracle as EO
     from oracle import host_oracle as HO
     torch.manual_seed(23)
-    sz = torch.randint(12, 41, (10,))
-    sz[3] = 40
+    sz = torch.randint(12, 34, (10,))            # n - 1 <= 32 rows: an atom spans at most three 16-row units
+    sz[3] = 33
     B, N = sz.numel(), 40
     nm, em = HO.masks_from_sizes(sz, N)
     z = torch.randn(B, N, 11) * nm
@@ -198,6 +198,27 @@ def test_mixed_four_tile_and_quarter_tile_units_vs_oracle(dyn, edm_sd, tail, mon
     ok, err, sc = close(out, ref)
     assert ok, f"MCG_TAIL={tail}: err {err} scale {sc}"
     assert float((out.cpu() * (1 - nm)).abs().max()) == 0.0
+
+
+def test_largest_molecules_span_four_quarter_tile_units(dyn, edm_sd, monkeypatch):
+    """42-atom molecules (the reference's pad width): an atom's 41 edge rows run through up to four one-tile units, so
+    the node GEMM gathers four rows of the workgroup-level sums and the coordinate update adds four."""
+    from oracle import egnn_oracle as EO
+    from oracle import host_oracle as HO
+    torch.manual_seed(29)
+    sz = torch.tensor([42, 41, 37, 42, 35])
+    B, N = sz.numel(), 42
+    nm, em = HO.masks_from_sizes(sz, N)
+    z = torch.randn(B, N, 11) * nm
+    ctx = torch.randn(B, 1, 3).repeat(1, N, 1) * nm
+    t = torch.full((B, 1), 0.3)
+    ref = EO.egnn_dynamics(edm_sd, t, z, nm, em, ctx)
+    for tail in ("-1", "24"):
+        monkeypatch.setenv("MCG_TAIL", tail)
+        plan = dyn.plan(sz, N, edge_mt=1)
+        out = dyn.run(plan, t.reshape(-1).to(DEV), z.to(DEV), ctx.to(DEV))
+        ok, err, sc = close(out, ref)
+        assert ok, f"MCG_TAIL={tail}: err {err} scale {sc}"
 
 
 @pytest.mark.parametrize("mt", [1, 2])
