@@ -68,9 +68,9 @@ __device__ __forceinline__ float mcg_silu(float x) { return x * mcg_sigmoid(x); 
 
 // SiLU of two values with the full-rate steps as PACKED fp32 instructions (v_pk_mul_f32 / v_pk_add_f32: two lanes'
 // worth of IEEE fp32 per issue slot); the two transcendentals stay scalar.  Bit-identical to mcg_silu per element in the
-// default MCG_PRECISE mode (the same multiply by -log2(e), v_exp_f32, add, v_rcp_f32, multiply).  Every VALU
-// instruction of the edge kernel runs beside a saturated matrix pipe (no co-issue on gfx950): halving the plain ones
-// is worth ~8 cycles per SiLU.
+// default MCG_PRECISE mode (the same multiply by -log2(e), v_exp_f32, add, v_rcp_f32, multiply).  Used by the
+// A-operand generation of the edge kernels (time-neutral there, fewer issued instructions); the same rewrite of the
+// EPILOGUE SiLUs measured 2.6 % slower at the config 3 shape (559 -> 575 us per launch) and was reverted.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 mcg_silu2(f32x2 x) {
 #if MCG_PRECISE != 0

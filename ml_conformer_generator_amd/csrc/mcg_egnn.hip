@@ -281,19 +281,18 @@ __device__ __forceinline__ void edge_epilogue_wg(const EdgeArgs& p, const WgSums
                                                  f32x4 (&acc)[1][NT], const RowInfo<1>& R, const float* b2p, const float* wvp,
                                                  float* sl) {
     const int g = lane >> 4, c = lane & 15;
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
     (void)b2p;                                                  // (the bias already sits in the accumulators: they start from it)
-    f32x2 part01 = {0.f, 0.f}, part23 = {0.f, 0.f};
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const float wv = wvp[nt * 16 + c];
-        // second Linear (+ bias, see k_edge_lds) + SiLU (egnn.py:26-27), two rows per packed instruction
-        const f32x2 m01 = mcg_silu2((f32x2){acc[0][nt][0], acc[0][nt][1]});
-        const f32x2 m23 = mcg_silu2((f32x2){acc[0][nt][2], acc[0][nt][3]});
-        acc[0][nt] = (f32x4){m01[0], m01[1], m23[0], m23[1]};
-        part01 = __builtin_elementwise_fma(m01, (f32x2){wv, wv}, part01);
-        part23 = __builtin_elementwise_fma(m23, (f32x2){wv, wv}, part23);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float m = mcg_silu(acc[0][nt][r]);           // second Linear (+ bias, see k_edge_lds) + SiLU (egnn.py:26-27)
+            acc[0][nt][r] = m;
+            part[r] = fmaf(wv, m, part[r]);
+        }
     }
-    const float part[4] = {part01[0], part01[1], part23[0], part23[1]};
     int rseg[4];
     float dot[4];
 #pragma unroll
@@ -533,17 +532,15 @@ __device__ __forceinline__ void edge_quarter_body(const EdgeArgs& p, int unit, i
     super(std::integral_constant<int, 2>{}, 8);
 
     // ---- epilogue on the wave's own column tiles
-    f32x2 part01 = {0.f, 0.f}, part23 = {0.f, 0.f};
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < QT; ++i) {
-        // second Linear (+ bias) + SiLU (egnn.py:26-27), two rows per packed instruction
-        const f32x2 m01 = mcg_silu2((f32x2){acc[i][0], acc[i][1]});
-        const f32x2 m23 = mcg_silu2((f32x2){acc[i][2], acc[i][3]});
-        acc[i] = (f32x4){m01[0], m01[1], m23[0], m23[1]};
-        part01 = __builtin_elementwise_fma(m01, (f32x2){wvr[i], wvr[i]}, part01);
-        part23 = __builtin_elementwise_fma(m23, (f32x2){wvr[i], wvr[i]}, part23);
-    }
-    float part[4] = {part01[0], part01[1], part23[0], part23[1]};
+    for (int i = 0; i < QT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float m = mcg_silu(acc[i][r]);                    // second Linear (+ bias) + SiLU (egnn.py:26-27)
+            acc[i][r] = m;
+            part[r] = fmaf(wvr[i], m, part[r]);
+        }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         part[r] = mcg_row16_sum(part[r]);
