@@ -674,9 +674,6 @@ __global__ __launch_bounds__(256) void mcg_gemm16_kernel(McgGemmArgs p) {
             const int gbytes = p.n_tiles * 256 * 4;
             auto load_group = [&](int slot, int q) {
                 q = q < groups ? q : groups - 1;
-#ifdef MCG_GX_NOLOAD
-                if (q > MCG_GX_NOLOAD) return;
-#endif
 #pragma unroll
                 for (int m = 0; m < MR; ++m) {
                     Ar[slot][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)oa[m], 64 * q, 0));
