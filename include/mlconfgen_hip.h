@@ -69,7 +69,8 @@ int mcg_egnn_set_precision(mcg_egnn* m, int mode);
  * ones, edge_mask = outer product minus diagonal.  edge_mt: 0 = auto, 1..2 = rows/16 per wave. */
 int mcg_plan_create(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_plan** out);
 /* Same, with the number of independent molecule ranges (each runs the whole denoiser on its own HIP stream inside
- * mcg_egnn_dynamics; 0 = the library's choice: 2 from 8 192 edge tiles on, 1 below) given by the caller. */
+ * mcg_egnn_dynamics; 0 = the library's choice: for 16-row-tile plans 1 / 2 / 3 / 4 ranges below 3 600 / 5 200 / 14 000 /
+ * from 14 000 edge tiles on, for 64-row-unit plans 2 from 8 192 tiles on) given by the caller. */
 int mcg_plan_create_ranges(int B, int N, const int32_t* n_nodes_host, int edge_mt, int n_ranges, mcg_plan** out);
 void mcg_plan_destroy(mcg_plan* p);
 /* Edge-kernel choice (exact-fp32 mode, edge_mt 1): -1 auto - the throughput kernel, whose workgroups take four 16-row

@@ -2337,13 +2337,19 @@ static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, i
     MCG_HIP(hipMalloc((void**)&p->t_buf, (size_t)B * sizeof(float)));
     p->allocs.push_back(p->t_buf);
     MCG_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
-    // Split the batch into `parts` molecule ranges of ~equal edge count, one HIP stream each.
-    // Measured (tools/bench_kernels.py): 2 ranges are 7 % faster at config 3 (12 k edge tiles = 12 rounds
-    // of the chip) but 12 % slower at config 2 (2.8 k tiles: halving them wrecks the tile quantisation),
-    // so the split is only taken when every range still fills the chip several times over.
-    // (The split-operand modes profit earlier - f32x6 at config 2: 3.53 -> 3.18 ms per call - because their edge
-    // kernel is short against the node phase; their host mirror asks for two ranges explicitly.)
-    int parts = n_ranges > 0 ? n_ranges : (p->n_mtiles >= 8192 ? 2 : 1);
+    // Split the batch into `parts` molecule ranges of ~equal edge count, one HIP stream each: the launch-bound node GEMMs
+    // of one range run under another range's edge kernel, and the ramps / tails of the edge kernels overlap.
+    // Exact-fp32 plans (16-row tiles), measured per denoiser call (tools/c3_split_sweep.sh; W = workgroup-equivalents =
+    // tiles / 4, 27-atom molecules unless noted):  W = 702 (config 2): 4.54 / 4.96 / 4.93 ms with 1 / 2 / 3 ranges;
+    // 1 053: 6.85 / 6.42 / 6.83;  1 229: 7.93 / 7.55 / 7.60;  1 404: 8.79 / 8.84 / 8.49;  2 106: 13.01 / 12.94 / 12.66;
+    // 2 808: 16.92 / 17.12 / 16.05 (4: 16.72);  3 005 (config 3 shape, ragged): - / 17.37 / 17.11 (4: 18.0);
+    // 4 212: 3 ranges 24.99, 4: 23.94, 5: 26.7.  Hence the table below.  Other plans (64-row units of the bf16 / split-operand
+    // kernels) keep round 1's rule; the split-operand modes' host mirror asks for two ranges explicitly (f32x6 at
+    // config 2: 3.53 -> 3.18 ms per call - their edge kernel is short against the node phase).
+    int parts = 1;
+    if (n_ranges > 0) parts = n_ranges;
+    else if (p->MT == 1) parts = p->n_mtiles < 3600 ? 1 : p->n_mtiles < 5200 ? 2 : p->n_mtiles < 14000 ? 3 : 4;
+    else parts = p->n_mtiles >= 8192 ? 2 : 1;
     if (const char* e = getenv("MCG_SPLIT")) parts = atoi(e);
     if (parts < 2 || B < 2 * parts || p->n_rows < 4096) return MCG_OK;
     std::vector<long> cum(B + 1, 0);

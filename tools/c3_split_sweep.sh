@@ -1,0 +1,8 @@
+#!/bin/bash
+# On the GPU box: one denoiser call (phi) at N molecules of 27 atoms for several range splits:  tools/c3_split_sweep.sh "64 96" "1 2 3"
+R=$GRAFT_REPO_ROOT
+for mols in $1; do
+for sp in $2; do
+  echo -n "[mols=$mols MCG_SPLIT=$sp] "; MCG_SPLIT=$sp python3 $R/tools/bench_kernels.py --mols $mols --iters 10 | sed 's/dtype=f32 shape=c2 mt=1//'
+done
+done
