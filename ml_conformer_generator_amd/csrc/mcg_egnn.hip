@@ -2339,7 +2339,7 @@ static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, i
     MCG_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
     // Split the batch into `parts` molecule ranges of ~equal edge count, one HIP stream each: the launch-bound node GEMMs
     // of one range run under another range's edge kernel, and the ramps / tails of the edge kernels overlap.
-    // Exact-fp32 plans (16-row tiles), measured per denoiser call (tools/c3_split_sweep.sh; W = workgroup-equivalents =
+    // Exact-fp32 plans (16-row tiles), measured per denoiser call (tools/split_sweep.sh; W = workgroup-equivalents =
     // tiles / 4, 27-atom molecules unless noted):  W = 702 (config 2): 4.54 / 4.96 / 4.93 ms with 1 / 2 / 3 ranges;
     // 1 053: 6.85 / 6.42 / 6.83;  1 229: 7.93 / 7.55 / 7.60;  1 404: 8.79 / 8.84 / 8.49;  2 106: 13.01 / 12.94 / 12.66;
     // 2 808: 16.92 / 17.12 / 16.05 (4: 16.72);  3 005 (config 3 shape, ragged): - / 17.37 / 17.11 (4: 18.0);

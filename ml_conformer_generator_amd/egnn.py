@@ -43,7 +43,8 @@ class BatchPlan:
         return self._h
 
     def set_latency_mode(self, mode: int) -> None:
-        """-1 auto, 0 always the throughput edge kernel, 1 always the column-split latency kernel."""
+        """-1 auto (four-tile workgroups for complete rounds of the chip, quarter-tile ones for the rest), 0 four-tile
+        workgroups only, 1 the stand-alone column-split kernel with per-wave partial sums (mcg_plan_set_latency_mode)."""
         _lib.check(_lib.lib().mcg_plan_set_latency_mode(self._h, int(mode)), "mcg_plan_set_latency_mode")
 
     def node_mask(self) -> torch.Tensor:

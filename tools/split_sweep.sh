@@ -1,5 +1,5 @@
 #!/bin/bash
-# On the GPU box: one denoiser call (phi) at N molecules of 27 atoms for several range splits:  tools/c3_split_sweep.sh "64 96" "1 2 3"
+# On the GPU box: one denoiser call (phi) at N molecules of 27 atoms for several range splits:  tools/split_sweep.sh "64 96" "1 2 3"
 R=$GRAFT_REPO_ROOT
 for mols in $1; do
 for sp in $2; do
