@@ -204,8 +204,10 @@ def make_generator(args, dev, dtype, sd, gsd):
 
 def timed_passes(gen, ctx, n_total, n_atoms, variance, frag_kw, steps, warmup, fence, seed=7):
     """`steps` timed calls of the public sharded path after `warmup` untimed ones.
-    Returns (elapsed seconds on this rank, mean sampler ms per pass, last result, last valid fraction)."""
+    Returns (elapsed seconds on this rank, mean sampler ms per pass, whether EVERY coordinate this rank generated in the
+    timed passes is finite, last valid fraction)."""
     sampler_ms = []
+    finite = [True]
 
     def one_pass():
         # sizes: CPU generator only (torch.manual_seed would also reseed every device generator and give all ranks
@@ -215,6 +217,9 @@ def timed_passes(gen, ctx, n_total, n_atoms, variance, frag_kw, steps, warmup, f
                                                n_samples=n_total, seed=seed, **frag_kw)
         torch.cuda.synchronize(gen.device)
         sampler_ms.append(gen._timing["sampler_start"].elapsed_time(gen._timing["sampler_end"]))
+        # (outside the sampler events, inside the wall clock: one reduction over this rank's [B, N, 3] result tensor)
+        if gen.last_batch is not None:
+            finite[0] = finite[0] and bool(torch.isfinite(gen.last_batch["x"]).all())
         return mols
 
     for _ in range(warmup):
@@ -226,7 +231,7 @@ def timed_passes(gen, ctx, n_total, n_atoms, variance, frag_kw, steps, warmup, f
     for _ in range(steps):
         mols = one_pass()
     fence()
-    return time.perf_counter() - t0, sum(sampler_ms) / max(1, len(sampler_ms)), mols, gen.last_valid_fraction
+    return time.perf_counter() - t0, sum(sampler_ms) / max(1, len(sampler_ms)), finite[0], gen.last_valid_fraction
 
 
 def x6_probe(args, gen, sd, gsd, ctx, dev):
@@ -245,8 +250,9 @@ def x6_probe(args, gen, sd, gsd, ctx, dev):
     o32 = gen.generative_model.dynamics(t, z, nm, None, c)
     o6 = g6.generative_model.dynamics(t, z, nm, None, c)
     dev_rel = float((o6 - o32).abs().max() / o32.abs().max())
-    el, ms, _, _ = timed_passes(g6, ctx, B, args.n_atoms, args.variance, {}, 1, 1, lambda: torch.cuda.synchronize(dev))
+    el, ms, fin6, _ = timed_passes(g6, ctx, B, args.n_atoms, args.variance, {}, 1, 1, lambda: torch.cuda.synchronize(dev))
     return {"value": B / el, "unit": "molecules/s", "egnn_step_ms_per_batch": ms / (args.diffusion_steps + 1),
+            "outputs_finite": fin6,
             "max_rel_deviation_of_one_denoiser_call_from_exact_fp32": dev_rel,
             "note": "opt-in mode, NOT the judged number: multiplies in bf16 (6 partial products of 3-part fp32 operands), "
                     "accumulates in fp32; passes the same fp32 parity tolerance as the exact kernel (DESIGN.md)"}
@@ -347,8 +353,12 @@ def main():
     from ml_conformer_generator_amd import weights as W
     from ml_conformer_generator_amd.synthetic import DUMMY_CONTEXT
 
-    # (fragment modes: contractive legacy weights - the mutation-checked default gains overflow under resampling)
-    sd = W.synth_edm_state_dict(1234, weight_gain=0.3) if args.fragment else W.synth_edm_state_dict(1234)
+    # Weights: the mutation-checked gains with the squared-distance columns damped ("v2d").  The undamped default
+    # ("v2", the parity fixtures' recipe at T = 20 / B = 4) overflows the UNTRAINED sampler at this workload - x -> d^2 ->
+    # x feeds back through the coordinate head and the trajectory is NaN from step ~30 of 100 (tools/finite_probe.py) -
+    # and a benchmark must not time NaN arithmetic.  `outputs_finite` below is checked on EVERY generated coordinate.
+    # (fragment modes: contractive legacy weights - resampling repeats the 1/alpha_ts amplification of the first step)
+    sd = W.synth_edm_state_dict(1234, weight_gain=0.3) if args.fragment else W.synth_edm_state_dict(1234, recipe="v2d")
     gsd = W.synth_adj_mat_seer_state_dict(4321)
     gen = make_generator(args, dev, args.dtype, sd, gsd)
     ctx = torch.tensor(DUMMY_CONTEXT)
@@ -365,13 +375,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    elapsed, sampler_ms, last, valid_frac = timed_passes(gen, ctx, B * world, args.n_atoms, args.variance, frag_kw,
-                                                         args.steps, args.warmup, fence)
+    elapsed, sampler_ms, finite, valid_frac = timed_passes(gen, ctx, B * world, args.n_atoms, args.variance, frag_kw,
+                                                           args.steps, args.warmup, fence)
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64,
+        tt = torch.tensor([elapsed, 0.0 if finite else 1.0], dtype=torch.float64,
                           device=dev if dist.get_backend() == "nccl" else torch.device("cpu"))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = float(tt[0].item())
+        finite = float(tt[1].item()) == 0.0            # every rank's shard
 
     if rank == 0:
         total_mols = B * world * args.steps
@@ -391,7 +402,6 @@ def main():
             pass
         plan, roof = edge_roofline(args, gen, dev, args.dtype, traffic, traffic_source)
         agg_s, agg_b = time_aggregate_kernel(plan, dev)
-        finite = all(bool(torch.isfinite(m.coords).all()) for m in last) if last is not None else False
         if B == 64 and args.variance == 0 and args.n_atoms == 27:
             cfg_label = "configs[1]"
         elif B == 256 and args.variance == 12 and args.n_atoms == 27:
@@ -420,7 +430,9 @@ def main():
                        "parallelism": (f"batch-sharded x{world}, " + ("RCCL" if backend == "nccl" else backend + " (dry run, ranks share the GPU)")
                                        + " all_gather at end") if world > 1 else "single GPU",
                        "edge_rows_per_wave": 16 * plan.edge_mt, "real_edges": plan.n_real_edges,
-                       "real_nodes": plan.n_real_nodes},
+                       "real_nodes": plan.n_real_nodes,
+                       "weights": "synthetic, reference checkpoint layout, seed 1234, " +
+                                  ("nn.Linear-family init x 0.3" if args.fragment else "recipe v2d (ml_conformer_generator_amd/weights.py)")},
             "dist_world_size": dist.get_world_size() if use_dist else 1,
             "dist_backend": (dist.get_backend() if use_dist else None),
             "timed_region": "MLConformerGenerator.generate_conformers_sharded: size draw, sampler, hand-off, GCN, bond "
@@ -444,12 +456,13 @@ def main():
                         and args.diffusion_steps == 100)
         if default_line and not args.no_config2:
             # BASELINE configs[2] (256 ragged molecules, 15..39 atoms) timed in the same run: 1 warm-up + 2 passes
-            el2, ms2, _, vf2 = timed_passes(gen, ctx, 256, 27, 12, {}, 2, 1, fence)
+            el2, ms2, fin2, vf2 = timed_passes(gen, ctx, 256, 27, 12, {}, 2, 1, fence)
             _, roof2 = edge_roofline(args, gen, dev, args.dtype)
             out["config2_ragged256"] = {
                 "workload": "configs[2] shape: n_samples=256, 27+-12 heavy atoms (ragged), diffusion_steps=100, " + mode_text,
                 "value": 256 * 2 / el2, "unit": "molecules/s", "steps": 2, "warmup": 1, "ms_per_step": el2 / 2 * 1e3,
-                "egnn_step_ms_per_batch": ms2 / (args.diffusion_steps + 1), "valid_proxy_fraction": vf2, "roofline": roof2}
+                "egnn_step_ms_per_batch": ms2 / (args.diffusion_steps + 1), "valid_proxy_fraction": vf2,
+                "outputs_finite": fin2, "roofline": roof2}
         if args.dtype == "f32" and world == 1 and not args.no_x6_probe and not args.fragment:
             out["f32x6_candidate"] = x6_probe(args, gen, sd, gsd, ctx, dev)
         if not args.no_cpu_baseline and world == 1:
@@ -469,6 +482,10 @@ def main():
         except Exception:  # noqa: BLE001
             pass
         print(line, flush=True)
+        if not finite:
+            sys.stderr.write("bench.py: the timed passes produced non-finite coordinates (`outputs_finite`: false) - "
+                             "the line above is NOT a valid measurement\n")
+            sys.exit(5)
 
 
 if __name__ == "__main__":

@@ -37,13 +37,14 @@ def close(a, b, rtol=1e-4, atol=1e-5):
 _DYN = {}
 
 
-def dyn_for(g):
-    """EGNNDynamics holding the weights a golden fixture was generated with."""
+def dyn_for(g, mode="f32"):
+    """EGNNDynamics holding the weights a golden fixture was generated with (one instance per operand mode)."""
     from ml_conformer_generator_amd.egnn import EGNNDynamics
-    key = (int(g["weight_seed"]), str(g["weight_recipe"]) if "weight_recipe" in g else "v2")
+    key = (int(g["weight_seed"]), str(g["weight_recipe"]) if "weight_recipe" in g else "v2", mode)
     if key not in _DYN:
         d = EGNNDynamics(device=DEV)
         d.load_reference_state_dict(sd_for(g))
+        d.set_precision(mode)
         _DYN[key] = d
     return _DYN[key]
 
@@ -57,8 +58,9 @@ def dyn(edm_sd):
 def sampler_factory(dyn):
     from ml_conformer_generator_amd.equivariant_diffusion import EquivariantDiffusion, PredefinedNoiseSchedule
 
-    def make(T, g=None):
-        gm = EquivariantDiffusion(dynamics=dyn if g is None else dyn_for(g), in_node_nf=8, timesteps=1000, noise_precision=1e-5)
+    def make(T, g=None, mode="f32"):
+        gm = EquivariantDiffusion(dynamics=dyn if (g is None and mode == "f32") else dyn_for(g if g is not None else {"weight_seed": 1234, "weight_recipe": "v2"}, mode),
+                                  in_node_nf=8, timesteps=1000, noise_precision=1e-5)
         gm.gamma = PredefinedNoiseSchedule(timesteps=T, precision=1e-5)
         gm.T = T
         return gm
@@ -300,11 +302,14 @@ def test_non_prefix_mask_rejected(dyn):
         dyn(torch.zeros(1, 1), torch.zeros(1, 5, 11), nm, torch.zeros(25, 1), torch.zeros(1, 5, 3))
 
 
+# (mode "f32x6": the opt-in split-operand kernels under the SAME per-step tolerance as the exact path - every golden
+#  trajectory of the reference: plain, resampling, inpainting, fragment merge)
+@pytest.mark.parametrize("mode", ["f32", "f32x6"])
 @pytest.mark.parametrize("name,rs", [("sampler_T20_b4n19.npz", 0), ("sampler_T8_rs1.npz", 1)])
-def test_sampler_trajectory_vs_golden(sampler_factory, name, rs):
+def test_sampler_trajectory_vs_golden(sampler_factory, name, rs, mode):
     g = load_golden(name)
     nm = g["node_mask"]
-    gm = sampler_factory(int(g["T"]), g)
+    gm = sampler_factory(int(g["T"]), g, mode)
     gm.noise_fn = TapeNoise(g["noise"], DEV)
     gm.trace = []
     x, h = gm(nm.to(DEV), edge_mask_of(nm).to(DEV), g["context"].to(DEV), rs)
@@ -339,10 +344,11 @@ def test_sampler_step_teacher_forced(sampler_factory):
     gm.noise_fn = None
 
 
-def test_inpaint_vs_golden(sampler_factory):
+@pytest.mark.parametrize("mode", ["f32", "f32x6"])
+def test_inpaint_vs_golden(sampler_factory, mode):
     g = load_golden("inpaint_T5.npz")
     nm = g["node_mask"]
-    gm = sampler_factory(int(g["T"]), g)
+    gm = sampler_factory(int(g["T"]), g, mode)
     gm.noise_fn = TapeNoise(g["noise"], DEV)
     gm.trace = []
     x, h = gm.inpaint(nm.to(DEV), edge_mask_of(nm).to(DEV), g["context"].to(DEV), g["z_known"], g["fixed_mask"], 1, 3)
@@ -426,10 +432,11 @@ def test_config5_share_ragged256_bf16_inpaint_properties():
     assert gen.generative_model.dynamics.plan(nm1.sum(1).reshape(-1).to(torch.int32).cpu(), 39).edge_mt == 4
 
 
-def test_merge_fragments_vs_golden(sampler_factory):
+@pytest.mark.parametrize("mode", ["f32", "f32x6"])
+def test_merge_fragments_vs_golden(sampler_factory, mode):
     g = load_golden("merge_T10_L10.npz")
     nm = g["node_mask"]
-    gm = sampler_factory(int(g["T"]), g)
+    gm = sampler_factory(int(g["T"]), g, mode)
     gm.noise_fn = TapeNoise(g["noise"], DEV)
     gm.trace = []
     x, h = gm.merge_fragments(nm.to(DEV), edge_mask_of(nm).to(DEV), g["fixed_mask"], g["context"].to(DEV),
@@ -1084,6 +1091,66 @@ def test_split_operand_modes_are_as_accurate_as_fp32_against_fp64(edm_sd):
     assert got["bf16"] > 20 * got["f32"]
 
 
+def test_split_operand_modes_under_cancellation_and_wide_dynamic_range_vs_fp64(edm_sd):
+    """Adversarial numerics for the split-operand contraction, ground truth = the oracle in fp64.
+    * Cancellation: every hidden layer is rebuilt so that channel k + 210 of its first Linear duplicates channel k, the
+      following Linear weighs the pair (w, -(1 + 2^-7) w) and has no bias: each 420-term dot product is then 128x smaller
+      than its positive and negative halves, and nothing else is added to it - what survives the cancellation is exactly
+      what a contraction that dropped low operand bits would get wrong.  The fp32 evaluations themselves lose 2-4
+      digits of the velocity here (1e-5 .. 1e-3 of its magnitude against fp64).
+    * Dynamic range: per-molecule feature scales from 1e-3 to 1e3, coordinate scales from 0.1 to 30.
+    f32x6 / f32x9 must sit at the same distance from fp64 as the exact fp32 kernel and the fp32 CPU evaluation do, per
+    molecule (each against its own magnitude) and separately for the velocity and the feature channels."""
+    from ml_conformer_generator_amd.egnn import EGNNDynamics
+    from oracle import egnn_oracle as EO
+    from oracle import host_oracle as HO
+    delta = 2.0 ** -7
+    sd = {k: v.clone() for k, v in edm_sd.items()}
+    for k in list(sd):
+        for first, second in (("edge_mlp.0.", "edge_mlp.2."), ("coord_mlp.0.", "coord_mlp.2."), ("node_mlp.0.", "node_mlp.2.")):
+            if k.endswith(first + "weight"):
+                base = k[: -len(first + "weight")]
+                sd[k][210:] = sd[k][:210]
+                sd[base + first + "bias"][210:] = sd[base + first + "bias"][:210]
+                w2 = sd[base + second + "weight"]
+                w2[:, 210:] = -(1.0 + delta) * w2[:, :210]
+                sd[base + second + "bias"].zero_()
+    sd64 = {k: v.double() for k, v in sd.items()}
+    torch.manual_seed(33)
+    B, N = 10, 30
+    sizes = torch.randint(12, 31, (B,))
+    nm, em = HO.masks_from_sizes(sizes, N)
+    z = torch.randn(B, N, 11) * nm
+    z[:, :, 3:] *= (10.0 ** torch.linspace(-3, 3, B)).view(B, 1, 1)          # features: six decades over the batch
+    z[:, :, :3] *= (10.0 ** torch.linspace(-1, 1.5, B)).view(B, 1, 1)        # coordinates: 0.1 .. 30
+    ctx = (torch.randn(B, 1, 3) * (10.0 ** torch.linspace(2, -2, B)).view(B, 1, 1)).repeat(1, N, 1) * nm
+    t = torch.rand(B, 1)
+    ref64 = EO.egnn_dynamics(sd64, t.double(), z.double(), nm.double(), em.double(), ctx.double())
+    ref32 = EO.egnn_dynamics(sd, t, z, nm, em, ctx)
+    assert bool(torch.isfinite(ref64).all())
+
+    def dev(o, sl):                    # per molecule, against ITS OWN magnitude: the scales differ by decades
+        e = (o.double() - ref64)[:, :, sl].flatten(1).pow(2).mean(1).sqrt()
+        return e / ref64[:, :, sl].flatten(1).abs().amax(1).clamp_min(1e-30)
+
+    groups = {"velocity": slice(0, 3), "features": slice(3, 11)}
+    base = {g: dev(ref32, sl) for g, sl in groups.items()}
+    assert float(base["velocity"].median()) > 3e-6     # the cancellation is visible: fp32 itself loses digits here
+    d = EGNNDynamics(device=DEV)
+    d.load_reference_state_dict(sd)
+    for mode in ("f32", "f32x9", "f32x6"):
+        d.set_precision(mode)
+        out = d(t.to(DEV), z.to(DEV), nm.to(DEV), em.to(DEV), ctx.to(DEV)).cpu()
+        assert bool(torch.isfinite(out).all())
+        for g, sl in groups.items():
+            v = dev(out, sl)
+            print(f"{mode:6s} {g:9s} deviation from fp64, median / max over molecules: {float(v.median()):.2e} / {float(v.max()):.2e}"
+                  f"   (fp32 CPU: {float(base[g].median()):.2e} / {float(base[g].max()):.2e})")
+            # rounding noise of a different summation order, not a lost operand bit: within 4x per molecule, 2x in the median
+            assert bool((v <= 4.0 * base[g] + 1e-7).all()), (mode, g, v.tolist(), base[g].tolist())
+            assert float(v.median()) <= 2.0 * float(base[g].median()) + 1e-7, (mode, g)
+
+
 def test_sampler_trajectory_in_f32x6_mode_vs_golden(edm_sd):
     """The reference sampler trajectory (golden, recorded noise tape) reproduced with the split-operand kernels:
     same tolerance as the exact-fp32 path (rel 1e-3 of max|z| per step, atom types exact)."""
@@ -1140,3 +1207,35 @@ def test_randomized_batch_shapes_vs_oracle(edm_sd, mode):
         else:
             ok, err, sc = close(out, ref)
             assert ok, (trial, B, sizes.tolist(), err, sc)
+
+
+def test_f32x6_end_to_end_equals_exact_path_on_a_contractive_network(gcn_sd):
+    """The whole generation (seeded size draw, T = 60 sampler, hand-off, GCN, bond argmax) in f32x6 and in exact fp32 from
+    the same seeds, on synthetic weights under which the sampler is contractive (nn.Linear-family init x 0.3): atom
+    types and the adjacency (bond-order argmax of the real lower triangle) must be IDENTICAL for every molecule and the
+    coordinates within 1e-5 of max|x|.  (On the expansive "v2d" weights the untrained sampler is chaotic - two exact-fp32
+    runs that differ by one ulp of the context end as far apart as f32x6 and fp32 do: tools/x6_end_to_end.py.)"""
+    from ml_conformer_generator_amd import MLConformerGenerator, weights as W
+    from ml_conformer_generator_amd.synthetic import DUMMY_CONTEXT
+    sd = W.synth_edm_state_dict(1234, weight_gain=0.3)
+    ctx = torch.tensor(DUMMY_CONTEXT)
+    res = {}
+    for mode in ("f32", "f32x6"):
+        gen = MLConformerGenerator(diffusion_steps=60, device=DEV, edm_weights=sd, adj_mat_seer_weights=gcn_sd, compute_dtype=mode)
+        for name, (n_samples, variance) in {"c1": (32, 0), "c2": (48, 12)}.items():
+            torch.default_generator.manual_seed(7)
+            torch.cuda.manual_seed(7)
+            gen._generate_shard(ctx, 27, variance, None, n_samples, 0, None, True, 3, 50)
+            res[(mode, name)] = {k: v.cpu() for k, v in gen.last_batch.items()}
+    for name in ("c1", "c2"):
+        a, b = res[("f32", name)], res[("f32x6", name)]
+        assert torch.equal(a["n_nodes"], b["n_nodes"])
+        assert bool(torch.isfinite(a["x"]).all()) and bool(torch.isfinite(b["x"]).all())
+        assert float((a["x"] - b["x"]).abs().max()) <= 1e-5 * float(a["x"].abs().max())
+        assert torch.equal(a["h"].argmax(2), b["h"].argmax(2))
+        assert torch.equal(a["elements"], b["elements"])
+        n = a["n_nodes"]
+        D = a["bond"].shape[1]
+        inside = (torch.arange(D).view(1, D, 1) < n.view(-1, 1, 1)) & (torch.arange(D).view(1, 1, D) < n.view(-1, 1, 1))
+        m = torch.tril(torch.ones(D, D, dtype=torch.bool), -1).unsqueeze(0) & inside
+        assert int(((a["bond"] != b["bond"]) & m).sum()) == 0
