@@ -1239,3 +1239,33 @@ def test_f32x6_end_to_end_equals_exact_path_on_a_contractive_network(gcn_sd):
         inside = (torch.arange(D).view(1, D, 1) < n.view(-1, 1, 1)) & (torch.arange(D).view(1, 1, D) < n.view(-1, 1, 1))
         m = torch.tril(torch.ones(D, D, dtype=torch.bool), -1).unsqueeze(0) & inside
         assert int(((a["bond"] != b["bond"]) & m).sum()) == 0
+
+
+@pytest.mark.parametrize("n_samples,variance", [(64, 0), (256, 12)])
+def test_bench_workload_stays_finite_over_100_steps(gcn_sd, n_samples, variance):
+    """The weights bench.py times (recipe "v2d") keep the untrained T = 100 sampler finite at configs[1] and at the
+    configs[2] shape - every latent of the trajectory and every output coordinate - so the benchmark does not time
+    NaN arithmetic.  (The parity fixtures' recipe "v2" overflows at this size from step ~30: asserted too, so that a
+    change of recipe that silently fixes or breaks either side is noticed.)"""
+    from ml_conformer_generator_amd import MLConformerGenerator, weights as W
+    from ml_conformer_generator_amd.synthetic import DUMMY_CONTEXT
+    ctx = torch.tensor(DUMMY_CONTEXT)
+    gen = MLConformerGenerator(diffusion_steps=100, device=DEV, edm_weights=W.synth_edm_state_dict(1234, recipe="v2d"),
+                               adj_mat_seer_weights=gcn_sd)
+    gm = gen.generative_model
+    gm.trace = []
+    torch.default_generator.manual_seed(7)
+    torch.cuda.manual_seed(7)
+    gen._generate_shard(ctx, 27, variance, None, n_samples, 0, None, True, 3, 50)
+    assert len(gm.trace) == 100
+    assert all(bool(torch.isfinite(z).all()) for z in gm.trace)
+    assert max(float(z.abs().max()) for z in gm.trace) < 1e5
+    assert bool(torch.isfinite(gen.last_batch["x"]).all())
+    gm.trace = None
+    if n_samples == 64:
+        bad = MLConformerGenerator(diffusion_steps=100, device=DEV, edm_weights=W.synth_edm_state_dict(1234),
+                                   adj_mat_seer_weights=gcn_sd)
+        torch.default_generator.manual_seed(7)
+        torch.cuda.manual_seed(7)
+        bad._generate_shard(ctx, 27, 0, None, 64, 0, None, True, 3, 50)
+        assert not bool(torch.isfinite(bad.last_batch["x"]).all())
