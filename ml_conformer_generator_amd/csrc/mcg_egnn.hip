@@ -1598,7 +1598,7 @@ struct mcg_plan {
     bool wgc = false;                       // tables below are valid and every workgroup touches <= 16 atoms
     struct UnitTables {
         int n_units = 0, n_full_wg = 0;     // workgroups of the throughput kernel; the first n_full_wg take four tiles, the rest one
-        int n_uslots = 0;                   // rows of U / Ux (+ one zero row at index n_uslots)
+        int n_uslots = 0;                   // rows of U / Ux this set writes (the common zero row sits behind the larger set's)
         int4* wg_info = nullptr;
         int4* node_slots = nullptr;         // per atom: its one to four rows of U (unused = the zero row)
         int max_span = 2;                   // most rows of U any atom has (3 / 4 only with quarter-tile units)
