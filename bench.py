@@ -78,13 +78,17 @@ def time_edge_kernel(gen, plan, dev, iters=20):
     dyn = gen.generative_model.dynamics
     stream = _lib.current_stream_ptr(dev)
     _lib.check(L.mcg_bench_edge(dyn.handle, plan.handle, 4, 0, 3, stream), "bench_edge")
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(dev)
-    e0.record()
-    _lib.check(L.mcg_bench_edge(dyn.handle, plan.handle, 4, 0, iters, stream), "bench_edge")
-    e1.record()
-    torch.cuda.synchronize(dev)
-    return e0.elapsed_time(e1) / iters * 1e-3
+    best = None
+    for _ in range(3):          # best of three batches of back-to-back launches (the first batch after the timed passes
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)      # runs 2-3 % slow)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        _lib.check(L.mcg_bench_edge(dyn.handle, plan.handle, 4, 0, iters, stream), "bench_edge")
+        e1.record()
+        torch.cuda.synchronize(dev)
+        sec = e0.elapsed_time(e1) / iters * 1e-3
+        best = sec if best is None else min(best, sec)
+    return best
 
 
 def time_aggregate_kernel(plan, dev, iters=20):
