@@ -78,6 +78,12 @@ void mcg_plan_destroy(mcg_plan* p);
  * for the whole of a small batch; 0 = four-tile workgroups only; 1 = the stand-alone column-split kernel with per-wave
  * partial sums (the fallback for plans without workgroup-level tables). */
 int mcg_plan_set_latency_mode(mcg_plan* p, int mode);
+/* Host-only self-check of the tables mcg_plan_create would build for a device with `cus` compute units (no GPU call;
+ * honours MCG_TAIL / MCG_EDGE_MT like mcg_plan_create): every edge row's (unit, tile, segment) must land in a slot its
+ * atom lists, no slot may be shared by two atoms, a four-tile unit parks <= 16 rows, the row table names the right
+ * (i, j).  info[8] = {table sets, units, four-tile units, slots, most slots per atom of set 0; units, slots, most slots
+ * per atom of set 1 (four-tile units only; zeros when there is one set)}.  Returns MCG_OK or an error with text. */
+int mcg_plan_check_tables(int B, int N, const int32_t* n_nodes_host, int edge_mt, int cus, int32_t* info_host);
 /* info[8] = {real nodes, real edges, edge_mt, edge waves, partial slots, B, N, 16-row edge tiles} */
 int mcg_plan_info(const mcg_plan* p, int32_t* info_host);
 

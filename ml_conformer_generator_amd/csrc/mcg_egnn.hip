@@ -2038,18 +2038,25 @@ void mcg_egnn_destroy(mcg_egnn* m) {
     delete m;
 }
 
-static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_plan** out) {
-    if (B < 1 || N < 1 || !n_nodes_host || !out) {
-        mcg_set_error("mcg_plan_create: bad arguments");
-        return MCG_ERR_ARG;
-    }
-    mcg_plan* p = new mcg_plan();
+// Everything of a plan that is HOST data - offsets, the row table, the unit tables of the throughput edge kernel - built
+// without touching the GPU (mcg_plan_check_tables runs it on a CPU-only box).  `cus`: compute units of the device the
+// plan is for (a round of the chip = 2 resident workgroups per CU).
+struct PlanHost {
+    std::vector<int> nn, node_off, row_off, node_mol, tile_mol, wave_poff, ij, node_slots;
+    struct Set { std::vector<int> wg_info, node_slots; int n_units = 0, n_full = 0, n_uslots = 0, span = 2; };
+    Set ht[2];                  // [0]: the automatic split into four-tile and quarter-tile units, [1]: four-tile units only
+    int n_sets = 0;
+    bool slots_ok = true, segs_ok = true;
+    int best = 1, R = 16;
+};
+
+static int plan_build_host(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, int edge_mt, int cus, PlanHost& H) {
     p->B = B; p->N = N;
-    std::vector<int> nn(B), node_off(B + 1, 0), row_off(B + 1, 0);
+    std::vector<int>&nn = H.nn, &node_off = H.node_off, &row_off = H.row_off;
+    nn.assign(B, 0); node_off.assign(B + 1, 0); row_off.assign(B + 1, 0);
     for (int b = 0; b < B; ++b) {
         if (n_nodes_host[b] < 0 || n_nodes_host[b] > N) {
             mcg_set_error("mcg_plan_create: n_nodes[%d]=%d outside [0,%d]", b, n_nodes_host[b], N);
-            delete p;
             return MCG_ERR_ARG;
         }
         nn[b] = n_nodes_host[b];
@@ -2060,7 +2067,6 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
         if (node_off[b + 1] > 1000000 || row_off[b + 1] > (1 << 30)) {
             mcg_set_error("mcg_plan_create: batch too large for one plan (%d atoms after molecule %d; limit 1e6 atoms, 2^30 edge rows)",
                           node_off[b + 1], b);
-            delete p;
             return MCG_ERR_ARG;
         }
     }
@@ -2076,8 +2082,10 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
     p->MT = best;
     p->n_waves = (p->n_mtiles + best - 1) / best;
     const int R = 16 * best;
+    H.best = best; H.R = R;
 
-    std::vector<int> node_mol(p->M), tile_mol(p->n_mtiles + 1, 0), wave_poff(p->n_waves + 1, 0);
+    std::vector<int>&node_mol = H.node_mol, &tile_mol = H.tile_mol, &wave_poff = H.wave_poff;
+    node_mol.assign(p->M, 0); tile_mol.assign(p->n_mtiles + 1, 0); wave_poff.assign(p->n_waves + 1, 0);
     for (int b = 0; b < B; ++b)
         for (int i = 0; i < nn[b]; ++i) node_mol[node_off[b] + i] = b;
     {
@@ -2092,9 +2100,11 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
     // <= 16 segments whatever the molecule sizes (1-atom molecules own node indices but no rows); every epilogue
     // handles segment ids 0..15, so wider units (edge_mt 2 / 4) are refused when a unit would need more.
     // Per-node partial-slot table node_slots[v][k] (ascending unit order = the order the sums are taken in).
-    std::vector<int> ij((size_t)(p->n_mtiles > 0 ? p->n_mtiles : 1) * 32, -1);
-    std::vector<int> node_slots((size_t)p->M * 8, -1);
-    bool slots_ok = true, segs_ok = true;
+    std::vector<int>&ij = H.ij, &node_slots = H.node_slots;
+    ij.assign((size_t)(p->n_mtiles > 0 ? p->n_mtiles : 1) * 32, -1);
+    node_slots.assign((size_t)p->M * 8, -1);
+    bool &slots_ok = H.slots_ok, &segs_ok = H.segs_ok;
+    slots_ok = segs_ok = true;
     {
         std::vector<int> unit_nseg(p->n_waves + 1, 0);
         std::vector<int> row_seg((size_t)p->n_rows, 0);
@@ -2210,11 +2220,11 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
         return true;
     };
     // table sets: [0] the automatic split, [1] four-tile units only (when different)
-    struct HostTables { std::vector<int> wg_info, node_slots; int n_units = 0, n_full = 0, n_uslots = 0, span = 2; };
-    HostTables ht[2];
-    int n_sets = 0;
+    PlanHost::Set (&ht)[2] = H.ht;
+    int& n_sets = H.n_sets;
+    n_sets = 0;
     auto keep = [&](int n_full) {
-        HostTables& t = ht[n_sets++];
+        PlanHost::Set& t = ht[n_sets++];
         t.wg_info = wg_info; t.node_slots = node_slots2; t.n_units = n_units; t.n_full = n_full;
         t.n_uslots = unit_sbase[n_units]; t.span = span;
     };
@@ -2226,9 +2236,6 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
         // (tools/tail_sweep.sh, 27-atom molecules): 702 workgroups 156.9 -> 148.3 us, 1053: 242.6 -> 209.4 us,
         // 351: 101.0 -> 88.7 us, 44: 55.8 -> 17.5 us.
         // MCG_TAIL=0 disables the quarter-tile units, MCG_TAIL=n forces n four-tile units, -1 none (measurement).
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        (void)hipGetLastError();
         const int round = 2 * (cus > 0 ? cus : 256);
         const int r = n_wg_all % round;
         int n_full = r * 512 <= 400 * round ? n_wg_all - r : n_wg_all;
@@ -2240,8 +2247,28 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
         wgc_ok = build_units(n_wg_all, 2);
         if (wgc_ok) keep(n_wg_all);
         else if (n_sets > 0) wgc_ok = true;         // (four-tile units alone would touch > 16 atoms: tiny molecules)
+        else if (build_units(0, 4)) { keep(0); wgc_ok = true; }     // ... then quarter-tile units only (16 rows: <= 16 atoms)
     }
     p->wgc = wgc_ok;
+    return MCG_OK;
+}
+
+static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_plan** out) {
+    if (B < 1 || N < 1 || !n_nodes_host || !out) {
+        mcg_set_error("mcg_plan_create: bad arguments");
+        return MCG_ERR_ARG;
+    }
+    mcg_plan* p = new mcg_plan();
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipGetLastError();
+    PlanHost H;
+    if (int e = plan_build_host(p, B, N, n_nodes_host, edge_mt, cus, H)) { delete p; return e; }
+    std::vector<int>&nn = H.nn, &node_off = H.node_off, &row_off = H.row_off, &node_mol = H.node_mol, &tile_mol = H.tile_mol,
+                    &wave_poff = H.wave_poff, &ij = H.ij, &node_slots = H.node_slots;
+    PlanHost::Set (&ht)[2] = H.ht;
+    const int n_sets = H.n_sets, best = H.best, R = H.R;
+    const bool slots_ok = H.slots_ok, segs_ok = H.segs_ok;
     if (!segs_ok) {
         mcg_set_error("mcg_plan_create: edge_mt = %d puts more than 16 atoms' rows into one %d-row unit (molecules this "
                       "small need edge_mt = 1)", best, R);
@@ -2299,6 +2326,92 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, int edg
         p->allocs.push_back(*b.ptr);
     }
     *out = p;
+    return MCG_OK;
+}
+
+// Host-only self-check of a plan's tables (no GPU call: it runs on a CPU-only box and is what the CPU tests drive):
+// builds them as mcg_plan_create would for a device with `cus` compute units and verifies, independently of how they
+// were built, that every edge row's (unit, tile, segment) lands in a slot that its atom lists, that no slot is shared
+// by two atoms, that a four-tile unit parks at most 16 rows, and that the row table names the right (i, j).
+int mcg_plan_check_tables(int B, int N, const int32_t* n_nodes_host, int edge_mt, int cus, int32_t* info /*[8]*/) {
+    if (B < 1 || N < 1 || !n_nodes_host || !info) { mcg_set_error("mcg_plan_check_tables: bad arguments"); return MCG_ERR_ARG; }
+    mcg_plan* p = new mcg_plan();
+    PlanHost H;
+    if (int e = plan_build_host(p, B, N, n_nodes_host, edge_mt, cus, H)) { delete p; return e; }
+    const int n_waves = p->n_waves, M = p->M, MT = p->MT;
+    const bool wgc = p->wgc;
+    delete p;
+    for (int k = 0; k < 8; ++k) info[k] = 0;
+    info[0] = H.n_sets;
+    if (!H.segs_ok || !H.slots_ok) { mcg_set_error("mcg_plan_check_tables: the batch does not fit the requested edge_mt"); return MCG_ERR_ARG; }
+    auto fail = [&](const char* what, int a, int b2) { mcg_set_error("mcg_plan_check_tables: %s (%d, %d)", what, a, b2); return MCG_ERR_STATE; };
+    // the row table
+    for (int b = 0; b < B; ++b) {
+        const int n = H.nn[b];
+        for (int i = 0; i < n && n > 1; ++i)
+            for (int jj = 0; jj < n - 1; ++jj) {
+                const size_t r = (size_t)H.row_off[b] + (size_t)i * (n - 1) + jj;
+                if (H.ij[2 * r] != H.node_off[b] + i) return fail("row table: wrong i", b, i);
+                if ((H.ij[2 * r + 1] & 0xffffff) != H.node_off[b] + jj + (jj >= i ? 1 : 0)) return fail("row table: wrong j", b, i);
+            }
+    }
+    if (!wgc) return MCG_OK;
+    if (MT != 1) return fail("workgroup-level tables on a plan that is not 16-row", MT, 0);
+    const int n_wg_all = (n_waves + 3) / 4;
+    for (int k = 0; k < H.n_sets; ++k) {
+        const PlanHost::Set& T = H.ht[k];
+        const int n_full = T.n_full;
+        const int n_tail = n_full < n_wg_all ? n_waves - 4 * n_full : 0;
+        if (T.n_units != n_full + n_tail) return fail("unit count", T.n_units, n_full + n_tail);
+        if ((int)T.wg_info.size() != 4 * T.n_units) return fail("wg_info size", (int)T.wg_info.size(), T.n_units);
+        int run = 0;
+        for (int w = 0; w < T.n_units; ++w) {
+            if (T.wg_info[4 * (size_t)w] != run) return fail("slot base not a running sum", w, run);
+            run += T.wg_info[4 * (size_t)w + 1];
+            if (w < n_full) {
+                int rows = 0;
+                for (int lt = 0; lt < 4; ++lt) rows += (T.wg_info[4 * (size_t)w + 3] >> (8 * lt)) & 0xff;
+                if (rows > 16) return fail("a four-tile unit parks more than 16 rows", w, rows);
+            }
+        }
+        if (run != T.n_uslots) return fail("slot total", run, T.n_uslots);
+        std::vector<int> owner((size_t)T.n_uslots, -1), hits((size_t)M * 4, 0);
+        int span_seen = 0;
+        for (int b = 0; b < B; ++b) {
+            const int n = H.nn[b];
+            for (int i = 0; i < n && n > 1; ++i) {
+                const int v = H.node_off[b] + i;
+                for (int jj = 0; jj < n - 1; ++jj) {
+                    const size_t r = (size_t)H.row_off[b] + (size_t)i * (n - 1) + jj;
+                    const int u = (int)(r / 16);
+                    const int w = u < 4 * n_full ? u / 4 : n_full + (u - 4 * n_full);
+                    const int lt = w < n_full ? u - 4 * w : 0;
+                    const int seg = H.ij[2 * r + 1] >> 24;
+                    const int ws0 = (T.wg_info[4 * (size_t)w + 2] >> (8 * lt)) & 0xff, ns = (T.wg_info[4 * (size_t)w + 3] >> (8 * lt)) & 0xff;
+                    if (seg < 0 || seg >= ns) return fail("segment id outside its tile's count", (int)r, seg);
+                    if (ws0 + seg >= T.wg_info[4 * (size_t)w + 1]) return fail("slot beyond the unit's count", (int)r, ws0 + seg);
+                    const int slot = T.wg_info[4 * (size_t)w] + ws0 + seg;
+                    if (owner[slot] >= 0 && owner[slot] != v) return fail("slot shared by two atoms", slot, v);
+                    owner[slot] = v;
+                    int found = -1;
+                    for (int q = 0; q < 4; ++q) if (T.node_slots[4 * (size_t)v + q] == slot) found = q;
+                    if (found < 0) return fail("row's slot missing from its atom's list", (int)r, slot);
+                    hits[4 * (size_t)v + found] = 1;
+                }
+                int used = 0;
+                for (int q = 0; q < 4; ++q) {
+                    const int sl = T.node_slots[4 * (size_t)v + q];
+                    if (sl >= 0) { if (!hits[4 * (size_t)v + q]) return fail("atom lists a slot none of its rows writes", v, sl); ++used; }
+                    for (int q2 = 0; q2 < q; ++q2) if (sl >= 0 && T.node_slots[4 * (size_t)v + q2] == sl) return fail("atom lists a slot twice", v, sl);
+                }
+                span_seen = std::max(span_seen, used);
+            }
+        }
+        for (int sl = 0; sl < T.n_uslots; ++sl) if (owner[sl] < 0) return fail("slot that no row writes", sl, k);
+        if (span_seen > T.span) return fail("an atom owns more rows of U than the set says", span_seen, T.span);
+        if (k == 0) { info[1] = T.n_units; info[2] = T.n_full; info[3] = T.n_uslots; info[4] = T.span; }
+        else { info[5] = T.n_units; info[6] = T.n_uslots; info[7] = T.span; }
+    }
     return MCG_OK;
 }
 

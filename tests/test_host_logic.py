@@ -224,3 +224,65 @@ def test_div100_three_fma_form_equals_ieee_division(tmp_path):
     r = subprocess.run([exe, "61"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout
     assert " 0 of them" in r.stdout
+
+
+def _check_tables(sizes, N, cus, edge_mt=1):
+    from ml_conformer_generator_amd import _lib
+    L = _lib.lib()
+    a = np.asarray(sizes, dtype=np.int32)
+    info = np.zeros(8, dtype=np.int32)
+    rc = L.mcg_plan_check_tables(len(a), int(N), a.ctypes.data, edge_mt, cus, info.ctypes.data)
+    return rc, info.tolist(), (L.mcg_last_error().decode() if rc else "")
+
+
+@pytest.mark.parametrize("tail", [None, "0", "-1", "8", "24"])
+def test_plan_unit_tables_are_consistent_for_random_batches(tail, monkeypatch):
+    """The host half of mcg_plan_create (no GPU): for random batch compositions, device sizes (`cus`) and splits between
+    four-tile and quarter-tile units, the library re-derives from the row table which (unit, tile, segment) every edge row
+    falls into and checks it against the tables the kernels read: the row's slot is listed by its atom, no slot serves
+    two atoms, every slot is written, a four-tile unit parks <= 16 rows, an atom lists at most as many slots as the
+    table set declares (<= 4)."""
+    if tail is None:
+        monkeypatch.delenv("MCG_TAIL", raising=False)
+    else:
+        monkeypatch.setenv("MCG_TAIL", tail)
+    g = torch.Generator().manual_seed(99)
+    for trial in range(24):
+        B = int(torch.randint(1, 40, (1,), generator=g))
+        lo, hi = [(2, 9), (6, 42), (15, 39), (1, 4), (27, 27), (40, 42)][trial % 6]
+        sizes = torch.randint(lo, hi + 1, (B,), generator=g).tolist()
+        N = max(sizes)
+        cus = [1, 2, 4, 16, 256][trial % 5]
+        rc, info, err = _check_tables(sizes, N, cus)
+        assert rc == 0, (trial, sizes, cus, err)
+        n_sets, units0, full0, slots0, span0, units1, slots1, span1 = info
+        rows = sum(n * (n - 1) for n in sizes)
+        if rows == 0:
+            continue
+        tiles = (rows + 15) // 16
+        wg_all = (tiles + 3) // 4
+        if n_sets == 0:          # no workgroup-level tables (an atom's rows span more than four units): per-wave partial path
+            assert max(sizes) > 42
+            continue
+        assert 1 <= n_sets <= 2 and 2 <= span0 <= 4
+        assert units0 == full0 + (tiles - 4 * full0 if full0 < wg_all else 0)
+        if n_sets == 2:
+            assert units1 == wg_all and span1 == 2 and slots1 <= slots0
+        if tail == "0" and n_sets == 1:      # four-tile units only - unless 64 rows would touch more than 16 (tiny) atoms
+            assert full0 == wg_all or (full0 == 0 and min(sizes) <= 6)
+
+
+def test_plan_unit_tables_at_the_bench_shapes():
+    """configs[1] on a 256-CU device: one complete round of 512 four-tile workgroups + 760 quarter-tile ones, atoms own at
+    most three rows of the sums; the alternative set is four-tile only (702 units, two rows per atom)."""
+    rc, info, err = _check_tables([27] * 64, 27, 256)
+    assert rc == 0, err
+    assert info == [2, 1272, 512, info[3], 3, 702, info[6], 2]
+    assert info[6] < info[3] < 2 * info[6]
+    # 42-atom molecules: 41 rows per atom run through up to four one-tile units
+    rc, info, err = _check_tables([42] * 6, 42, 256)
+    assert rc == 0, err
+    assert info[2] == 0 and info[4] == 4
+    # wide units cannot hold 33 two-atom molecules (64 row-owning atoms in one 64-row unit): refused, with a message
+    rc, info, err = _check_tables([2] * 33, 2, 256, edge_mt=4)
+    assert rc != 0 and "edge_mt" in err
