@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void k_edge_lds(EdgeArgs p)
     // them with a __syncthreads: that put one more memory round trip at the head of every workgroup); they are
     // read only after the main loop, whose first barrier (vmcnt(0) + lgkmcnt(0)) publishes them.
     for (int i = threadIdx.x; i < HP; i += 256) {
-        lds[2 * GROUP_LDS_FLOATS + i] = p.b2[i];
+        if constexpr (!WGC) lds[2 * GROUP_LDS_FLOATS + i] = p.b2[i];      // (WGC: the bias already sits in the accumulators)
         lds[2 * GROUP_LDS_FLOATS + HP + i] = p.wv[i];
     }
     f32x4 a4[MT];
