@@ -102,12 +102,21 @@ class EquivariantDiffusion(torch.nn.Module):
             dev = model.device
             self.B, self.N = int(node_mask.shape[0]), int(node_mask.shape[1])
             self.plan: BatchPlan = model.dynamics.plan(sizes_from_node_mask(node_mask), self.N)
-            self.context = context.to(dev, torch.float32).contiguous()
+            # Latent, network output and context live in buffers owned by the (cached) plan: the denoiser call is a HIP
+            # graph keyed by these addresses, so a second sampling run over the same batch shape replays the captured
+            # graph instead of re-capturing it (or, from the third run on, paying three staging copies per call).
+            sc = getattr(self.plan, "_sampler_scratch", None)
+            if sc is None:
+                sc = {k: torch.empty((self.B, self.N, w), device=dev, dtype=torch.float32) for k, w in (("z", 11), ("eps", 11), ("ctx", 3))}
+                self.plan._sampler_scratch = sc
+            self.context = sc["ctx"]
+            self.context.copy_(context.to(dev, torch.float32).reshape(self.B, self.N, 3))
+            self.z_buf = sc["z"]
             T = model.T
             # t value of every level 0..T, as float32(level)/T  (:388-391)
             levels = torch.arange(0, T + 1).to(torch.float32) / T
             self.t_table = levels.unsqueeze(1).repeat(1, self.B).to(dev).contiguous()   # [T+1, B]
-            self.eps_hat = torch.empty((self.B, self.N, 11), device=dev, dtype=torch.float32)
+            self.eps_hat = sc["eps"]
             self.stream = _lib.current_stream_ptr(dev)
 
     def sample_combined_position_feature_noise(self, n_samples: int, n_nodes: int, node_mask) -> torch.Tensor:
@@ -115,9 +124,9 @@ class EquivariantDiffusion(torch.nn.Module):
         run = self._Run(self, node_mask, torch.zeros(n_samples, n_nodes, 3))
         return self._noise(run)
 
-    def _noise(self, run: "_Run") -> torch.Tensor:
+    def _noise(self, run: "_Run", out: Optional[torch.Tensor] = None) -> torch.Tensor:
         rx, rh = self._draw(run.B, run.N)
-        eps = torch.empty((run.B, run.N, 11), device=self.device, dtype=torch.float32)
+        eps = out if out is not None else torch.empty((run.B, run.N, 11), device=self.device, dtype=torch.float32)
         _lib.check(_lib.lib().mcg_sampler_noise(run.plan.handle, _lib.dptr(rx), _lib.dptr(rh), _lib.dptr(eps),
                                                 run.stream), "mcg_sampler_noise")
         return eps
@@ -168,7 +177,7 @@ class EquivariantDiffusion(torch.nn.Module):
     def forward(self, node_mask, edge_mask, context, resample_steps: int = 0):
         """Draw samples (:365-421): T*(1+resample_steps) network calls + 1 decode call."""
         run = self._Run(self, node_mask, context)
-        z = self._noise(run)
+        z = self._noise(run, out=run.z_buf)
         for s_int in range(self.T - 1, -1, -1):
             for _ in range(resample_steps + 1):
                 z = self._step(run, z, s_int)
@@ -182,7 +191,7 @@ class EquivariantDiffusion(torch.nn.Module):
         run = self._Run(self, node_mask, context)
         zk = z_known.to(self.device, torch.float32).contiguous()
         fm = fixed_mask.to(self.device, torch.float32).contiguous()
-        z = self._noise(run)
+        z = self._noise(run, out=run.z_buf)
         for s_int in range(self.T - 1, -1, -1):
             for _ in range(resample_steps):
                 z = self._step(run, z, s_int)
@@ -201,8 +210,7 @@ class EquivariantDiffusion(torch.nn.Module):
         run = self._Run(self, node_mask, context)
         zk = z_known.to(self.device, torch.float32).contiguous()
         fm = fixed_mask.to(self.device, torch.float32).contiguous()
-        z = torch.empty((run.B, run.N, 11), device=self.device, dtype=torch.float32)
-        z = self._blend(run, z, zk, None, diffusion_level, blend_power, 0)
+        z = self._blend(run, run.z_buf, zk, None, diffusion_level, blend_power, 0)
         for s_int in range(self.T - 1, -1, -1):
             if s_int > diffusion_level:
                 continue
