@@ -486,6 +486,102 @@ def test_adj_mat_seer_full_size_properties(gcn):
     assert torch.equal(one[0], logits[5])
 
 
+def test_adj_mat_seer_b64_vs_oracle(gcn, gcn_sd):
+    """AdjMatSeer at the BASELINE batch size (B = 64, 15..39 atoms) against the oracle on every logit (rtol 1e-4 /
+    atol 1e-5 of max|logits|), bond argmax bit-exact wherever the oracle's top-2 margin exceeds 1e-3 (and the number of
+    entries below that margin is reported).  The oracle needs ~0.2 s for this."""
+    from ml_conformer_generator_amd.synthetic import synth_gcn_inputs
+    from oracle import gcn_oracle as GO
+    sizes = [15 + (i * 7) % 25 for i in range(64)]
+    el, dm, am = synth_gcn_inputs(64, sizes, seed=3)
+    ref = GO.adj_mat_seer(gcn_sd, el, dm, am)
+    bond, logits = gcn.bond_orders(el, dm, am, with_logits=True)
+    ok, err, sc = close(logits, ref, rtol=1e-4, atol=1e-5)
+    assert ok, f"logits err {err} scale {sc}"
+    top2 = torch.topk(ref, 2, dim=-1).values
+    margin = top2[..., 0] - top2[..., 1]
+    safe = margin > 1e-3
+    assert float(safe.float().mean()) > 0.9
+    got = bond.cpu().to(torch.int64)
+    assert torch.equal(got[safe], ref.argmax(-1)[safe])
+    n_diff = int((got != ref.argmax(-1)).sum())
+    print(f"B=64 GCN: max|logit err| {err:.2e} (scale {sc:.2e}); {int((~safe).sum())} of {safe.numel()} entries below the 1e-3 "
+          f"margin; argmax differs on {n_diff} entries in total")
+    assert n_diff <= int((~safe).sum())
+
+
+@pytest.mark.parametrize("name", ["e2e_T20_b4n19.npz", "e2e_T8_b8n27.npz"])
+def test_generate_path_end_to_end_vs_reference_golden(sampler_factory, gcn, gcn_sd, name):
+    """north_star's parity clause on the COMPOSED path (conformer_generator.py:330-366; mol_utils.py:146-194,210-211):
+    HIP sampler under the reference's recorded noise tape -> mcg_handoff -> mcg_gcn_forward -> bond argmax ->
+    mcg_bond_writeback, against what the reference's own EquivariantDiffusion and AdjMatSeer produce from that tape
+    (tools/make_golden.py section 8; RDKit's two decisions replaced by the labelled substitutes of
+    oracle/host_oracle.py:adj_mat_seer_input on BOTH sides).
+    Stated: atom types and elements exact; x within the trajectory tolerance (1e-3 of max|x|); distances follow x;
+    connectivity input exact except pairs whose distance sits within the x error of its threshold; logits within 1e-3 of
+    max|logits|; adjacency argmax (bond orders) EQUAL on every entry whose reference top-2 margin exceeds 100x the
+    measured logit error - the excluded share is printed and must stay below 1 %; the mirrored lower-triangle write-back
+    equals the oracle's write-back of the reference argmax on those entries."""
+    from ml_conformer_generator_amd.handoff import bond_writeback_hip, prepare_adj_mat_seer_input_hip
+    from oracle import host_oracle as HO
+    g = load_golden(name)
+    nm = g["node_mask"]
+    gm = sampler_factory(int(g["T"]), g, "f32")
+    gm.noise_fn = TapeNoise(g["noise"], DEV)
+    x, h = gm(nm.to(DEV), edge_mask_of(nm).to(DEV), g["context"].to(DEV), 0)
+    gm.noise_fn = None
+    assert torch.equal(h.cpu().to(torch.int64), g["h"].to(torch.int64))                       # atom types exact
+    vx = traj_violation(x.cpu().unsqueeze(0), g["x"].unsqueeze(0), split=None)
+    assert vx <= 1.0, f"x at {vx} x tolerance"
+    x_err = float((x.cpu() - g["x"]).abs().max())
+    n_nodes = g["n_nodes"]
+    el, dm, am = prepare_adj_mat_seer_input_hip(x, h, n_nodes.to(DEV))
+    assert torch.equal(el.cpu(), g["elements"])
+    d_err = float((dm.cpu() - g["dist_mat"]).abs().max())
+    assert d_err <= 4.0 * x_err + 1e-5, (d_err, x_err)
+    rc = torch.zeros(36)
+    for z, r in HO._RCOV.items():
+        rc[z] = r
+    thr = 1.3 * (rc[g["elements"]].unsqueeze(1) + rc[g["elements"]].unsqueeze(2))
+    borderline = ((g["dist_mat"] - thr).abs() <= 4.0 * x_err + 1e-5) & (thr > 0)
+    assert torch.equal(am.cpu()[~borderline], g["adj_mat"][~borderline])
+    am_equal = torch.equal(am.cpu(), g["adj_mat"])
+    assert am_equal, f"connectivity input differs on {int((am.cpu() != g['adj_mat']).sum())} borderline pairs"
+    bond, logits = gcn.bond_orders(el, dm, am, with_logits=True)
+    l_err = float((logits.cpu() - g["logits"]).abs().max())
+    l_sc = float(g["logits"].abs().max())
+    assert l_err <= 1e-3 * l_sc, (l_err, l_sc)
+    D = g["elements"].shape[1]
+    inside = (torch.arange(D).view(1, D, 1) < n_nodes.view(-1, 1, 1)) & (torch.arange(D).view(1, 1, D) < n_nodes.view(-1, 1, 1))
+    safe = g["margin"] > 100.0 * l_err
+    got = bond.cpu().to(torch.int64)
+    assert torch.equal(got[safe], g["argmax"][safe])                                         # adjacency indices bit-exact
+    excluded = float((~safe & inside).sum()) / float(inside.sum())
+    n_diff = int(((got != g["argmax"]) & inside).sum())
+    print(f"{name}: x err {x_err:.2e} (max|x| {float(g['x'].abs().max()):.1f}), dist err {d_err:.2e}, logit err {l_err:.2e} "
+          f"(scale {l_sc:.2e}); {100 * excluded:.3f} % of the in-molecule entries are below 100x that error; "
+          f"bond argmax differs from the reference on {n_diff} in-molecule entries")
+    assert excluded < 0.01
+    sym, _ = bond_writeback_hip(bond, el, n_nodes.to(DEV))
+    sym_ref, _ = HO.bond_writeback(g["argmax"], g["elements"], n_nodes)
+    low = torch.tril(torch.ones(D, D, dtype=torch.bool), -1).unsqueeze(0) & inside
+    both = low & safe & safe.transpose(1, 2)
+    assert torch.equal(sym.cpu()[both], sym_ref[both])
+    if n_diff == 0:
+        assert torch.equal(sym.cpu(), sym_ref)
+    # the same chain against the ORACLE pipeline driven by the same tape (sampler -> hand-off -> GCN), every stage
+    from oracle import diffusion_oracle as DO
+    from oracle import gcn_oracle as GO
+    orc = DO.SamplerOracle(sd_for(g), int(g["T"]), noise_fn=TapeNoise(g["noise"]))
+    xo, ho = orc.forward(nm, edge_mask_of(nm), g["context"], 0)
+    elo, dmo, amo = HO.adj_mat_seer_input(xo, ho, n_nodes)
+    lo = GO.adj_mat_seer(gcn_sd, elo, dmo, amo)
+    assert torch.equal(el.cpu(), elo) and torch.equal(am.cpu(), amo)
+    assert float((logits.cpu() - lo).abs().max()) <= 1e-3 * l_sc
+    safe_o = (torch.topk(lo, 2, dim=-1).values[..., 0] - torch.topk(lo, 2, dim=-1).values[..., 1]) > 100.0 * l_err
+    assert torch.equal(got[safe_o], lo.argmax(-1)[safe_o])
+
+
 def test_aggregate_standalone(edm_sd):
     from ml_conformer_generator_amd import _lib
     from oracle.egnn_oracle import aggregate_standalone
@@ -778,7 +874,7 @@ def test_ifm_merge_kernel_vs_oracle_and_golden():
 
 def test_config3_ragged_batch_subset_vs_oracle_and_determinism(dyn, edm_sd):
     """BASELINE configs[2] shape: 256 ragged molecules (15..39 atoms, N = 39), full size on the GPU
-    (two-stream split active).  The oracle needs ~1 min per call at this size, so parity is checked on a
+    (the plan cuts it into three molecule ranges on three streams).  The oracle needs ~1 min per call at this size, so parity is checked on a
     subset of molecules (every sample is independent), plus bit-exact determinism of the whole batch."""
     from oracle import egnn_oracle as EO
     from oracle import host_oracle as HO
@@ -790,7 +886,7 @@ def test_config3_ragged_batch_subset_vs_oracle_and_determinism(dyn, edm_sd):
     ctx = torch.tensor([-0.99, -1.66, -1.66]).view(1, 1, 3).repeat(B, N, 1) * nm
     t = torch.full((B, 1), 0.61)
     plan = dyn.plan(sizes, N)
-    assert plan.n_edge_tiles >= 8192          # large enough for the 2-stream split
+    assert plan.n_edge_tiles >= 5200          # large enough for the plan's automatic split into three ranges
     out1 = dyn.run(plan, t.reshape(-1).to(DEV), z.to(DEV), ctx.to(DEV)).cpu()
     out2 = dyn.run(plan, t.reshape(-1).to(DEV), z.to(DEV), ctx.to(DEV)).cpu()
     assert torch.equal(out1, out2) and torch.isfinite(out1).all()

@@ -128,6 +128,28 @@ def test_adj_mat_seer(gcn_sd):
     assert torch.equal(logits, logits.transpose(1, 2))
 
 
+@pytest.mark.parametrize("name", ["e2e_T20_b4n19.npz", "e2e_T8_b8n27.npz"])
+def test_composed_path_oracle_vs_reference(name, gcn_sd):
+    """The COMPOSED path of generate_conformers (conformer_generator.py:330-366): sampler (recorded noise tape) ->
+    hand-off tensors -> AdjMatSeer -> bond argmax.  The fixture holds what the reference's own EquivariantDiffusion and
+    AdjMatSeer produce (tools/make_golden.py section 8); the oracle pipeline must land on the same adjacency."""
+    g = load_golden(name)
+    nm = g["node_mask"]
+    orc = DO.SamplerOracle(sd_for(g), int(g["T"]), noise_fn=TapeNoise(g["noise"]))
+    x, h = orc.forward(nm, edge_mask_of(nm), g["context"], 0)
+    assert traj_violation(x.unsqueeze(0), g["x"].unsqueeze(0), split=None) <= 1.0
+    assert torch.equal(h.to(torch.int64), g["h"].to(torch.int64))
+    el, dm, am = HO.adj_mat_seer_input(x, h, g["n_nodes"])
+    assert torch.equal(el, g["elements"]) and torch.equal(am, g["adj_mat"])
+    assert torch.allclose(dm, g["dist_mat"], rtol=1e-5, atol=1e-4)
+    logits = GO.adj_mat_seer(gcn_sd, el, dm, am)
+    err = float((logits - g["logits"]).abs().max())
+    assert err <= 1e-4 * float(g["logits"].abs().max())
+    safe = g["margin"] > 100 * max(err, 1e-9)
+    assert torch.equal(logits.argmax(-1)[safe], g["argmax"][safe]) and float(safe.float().mean()) > 0.99
+    assert int((am.sum((1, 2)) - 42).min()) > 0                     # every molecule has perceived bonds: a non-trivial GCN input
+
+
 def test_shape_tanimoto_oracle_matches_reference():
     import numpy as np
     from oracle import shape_oracle as SO

@@ -98,6 +98,8 @@ from ml_conformer_generator_amd.synthetic import synth_gcn_inputs  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--only", default="", help="write only the fixtures whose file name contains this substring "
+                                               "(everything is still computed: the fixtures share RNG state and models)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
@@ -106,6 +108,8 @@ def main():
     dummy_ctx = torch.tensor([53.6424, 108.3042, 151.4399])
 
     def save(name, **kw):
+        if args.only and args.only not in name:
+            return
         np.savez_compressed(os.path.join(args.out, name), **{k: (v.numpy() if torch.is_tensor(v) else np.asarray(v))
                                                               for k, v in kw.items()})
         print("wrote", name, {k: tuple(np.asarray(v.numpy() if torch.is_tensor(v) else v).shape) for k, v in kw.items()})
@@ -178,6 +182,22 @@ def main():
         x, h = gm(nm, em, ctx, 0)
     save("sampler_T20_b4n19.npz", node_mask=nm, context=ctx, noise=tape.flat(), z_trace=torch.stack(trace),
          x=x, h=h, T=20, resample_steps=0, weight_seed=1234, weight_recipe=np.array("v2"))
+    e2e_runs = {"e2e_T20_b4n19.npz": dict(node_mask=nm, context=ctx, noise=tape.flat(), x=x, h=h, T=20, weight_seed=1234,
+                                          weight_recipe=np.array("v2"))}
+
+    # 5a. a second composed-path run at the BASELINE configs[1] molecule size (8 x 27 atoms, T = 8): see section 8 below.
+    #     (recipe "v2": its final coordinates stay at bond-length scale, so the hand-off perceives bonds - 22..148 per
+    #     molecule; the contractive "x 0.3" weights end at max|x| ~ 400 with no bond at all, a GCN input of identity
+    #     adjacencies that would pin nothing.)
+    #     T = 8: a one-ulp change of the context moves the final x by 1.5e-5 of max|x| (T = 12: 4e-4 - the untrained
+    #     sampler amplifies rounding differences with every step), far inside the stated 1e-3 trajectory tolerance.
+    gm = build_edm(egnn, ed, 8, sd)
+    torch.manual_seed(33)
+    nm, em, ctx = mu.prepare_edm_input(8, dummy_ctx, norms, 27, 27, torch.device("cpu"))
+    with NoiseTape() as tape, torch.no_grad():
+        x, h = gm(nm, em, ctx, 0)
+    e2e_runs["e2e_T8_b8n27.npz"] = dict(node_mask=nm, context=ctx, noise=tape.flat(), x=x, h=h, T=8, weight_seed=1234,
+                                         weight_recipe=np.array("v2"))
 
     # 5b. resampling variant (T=8, resample_steps=1) - "v2d" weights: see ml_conformer_generator_amd/weights.py
     sd_d = W.synth_edm_state_dict(1234, recipe="v2d")
@@ -310,6 +330,26 @@ def main():
     save("adj_mat_seer_b4.npz", elements=el, dist_mat=dm, adj_mat=am, logits=logits,
          argmax=torch.argmax(logits, -1), margin=margin, weight_seed=4321)
     print("min top-2 margin over all entries:", float(margin.min()))
+
+    # 8. the COMPOSED path of generate_conformers (conformer_generator.py:330-366): reference sampler output (x, h of
+    #    sections 5 / 5a, recorded noise tape) -> samples_to_rdkit_mol + prepare_adj_mat_seer_input (mol_utils.py:18-57,
+    #    146-194; RDKit is absent, so their tensor half is oracle/host_oracle.py:adj_mat_seer_input with its two labelled
+    #    substitutes - covalent-radius connectivity, generation order) -> the REFERENCE's AdjMatSeer.forward -> the
+    #    consumer's argmax (mol_utils.py:210).  Pins sampler -> hand-off -> GCN -> bond argmax end to end.
+    from oracle import host_oracle as HO
+    for name, r in e2e_runs.items():
+        n_nodes = r["node_mask"].sum(1).reshape(-1).to(torch.long)
+        el, dm, am = HO.adj_mat_seer_input(r["x"], r["h"], n_nodes)
+        with torch.no_grad():
+            logits = gcn(el, dm, am)
+        top2 = torch.topk(logits, 2, dim=-1).values
+        margin = top2[..., 0] - top2[..., 1]
+        save(name, **r, n_nodes=n_nodes, elements=el, dist_mat=dm, adj_mat=am, logits=logits,
+             argmax=torch.argmax(logits, -1), margin=margin, gcn_weight_seed=4321)
+        D = el.shape[1]
+        inside = (torch.arange(D).view(1, D, 1) < n_nodes.view(-1, 1, 1)) & (torch.arange(D).view(1, 1, D) < n_nodes.view(-1, 1, 1))
+        print(name, "bonds perceived per molecule:", (am.sum((1, 2)) - D).tolist(), " min margin inside molecules:",
+              float(margin[inside].min()), " max|x|:", float(r["x"].abs().max()))
 
 
 if __name__ == "__main__":
