@@ -75,15 +75,22 @@ class MLConformerGenerator(torch.nn.Module):
         generative_model.load_state_dict(_load_state_dict(edm_weights, device))
         net_dynamics.set_precision(compute_dtype)      # opt-in: "bf16" reduced-precision operands, "f32x6" split-operand fp32
         adj_mat_seer.load_state_dict(_load_state_dict(adj_mat_seer_weights, device))
-        # re-wire the schedule to the requested number of steps (conformer_generator.py:105-113)
-        generative_model.gamma = PredefinedNoiseSchedule(timesteps=diffusion_steps, precision=NOISE_PRECISION)
-        generative_model.time_steps = torch.flip(torch.arange(0, diffusion_steps), dims=[0])
-        generative_model.T = diffusion_steps
         self.generative_model = generative_model
+        self.set_diffusion_steps(diffusion_steps)
         self.adj_mat_seer = adj_mat_seer
         self.last_batch = None       # tensors of the most recent generation (x, h, n_nodes, bond)
         self.last_valid_fraction = None   # share of the last batch that passed the validity proxy
+        self.last_noise_seed = None       # device-generator seed of the last sharded call on this rank
         self._timing = None          # bench.py: {"sampler_start", "sampler_end"} events recorded around the sampler
+
+    def set_diffusion_steps(self, diffusion_steps: int) -> None:
+        """Re-wire the noise schedule to `diffusion_steps` denoising steps, exactly as the reference's constructor does
+        (conformer_generator.py:105-113); weights, plans and captured graphs are untouched."""
+        gm = self.generative_model
+        gm.gamma = PredefinedNoiseSchedule(timesteps=diffusion_steps, precision=NOISE_PRECISION)
+        gm.time_steps = torch.flip(torch.arange(0, diffusion_steps), dims=[0])
+        gm.T = diffusion_steps
+        self.diffusion_steps = diffusion_steps
 
     # ------------------------------------------------------------------ EDM stage
     @torch.no_grad()
@@ -219,8 +226,9 @@ class MLConformerGenerator(torch.nn.Module):
         SURVEY.md section 8e).  The global size vector is drawn once on rank 0 and broadcast, rank r generates
         the contiguous slice `shard_range(n_samples, r, world)`, and ONE all-gather of the result tensors at the
         end gives every rank the full batch, in sample order.  `seed`: per-rank noise seed `seed + rank` for the
-        device generator (None leaves the generators alone).  Without an initialised group this is
-        `generate_conformers`."""
+        device generator; None (default) = a base seed drawn on rank 0 and broadcast, so that ranks NEVER share a noise
+        stream (every process starts its device generator from the same constant).  A rank whose shard fails makes
+        every rank raise `distributed.ShardError`.  Without an initialised group this is `generate_conformers`."""
         ref_context, ref_n_atoms = self._reference_context(reference_conformer, reference_context, n_atoms)
         lo_n = max(ref_n_atoms - variance, self.min_n_nodes)
         hi_n = min(ref_n_atoms + variance, self.max_n_nodes)
@@ -230,6 +238,7 @@ class MLConformerGenerator(torch.nn.Module):
                                         fixed_fragment, inertial_fragment_matching, blend_power, ifm_diffusion_level)
 
         def seed_device(s):
+            self.last_noise_seed = s          # this rank's noise stream (base seed + rank)
             if self.device.type == "cuda":
                 with torch.cuda.device(self.device):
                     torch.cuda.manual_seed(s)

@@ -10,8 +10,11 @@ Molecule sizes: the GLOBAL size vector is drawn ONCE, on rank 0, from the CPU gl
 reference's own draw (`torch.randint(min, max + 1, (n_samples,))`, mol_utils.py:275) and broadcast
 (control plane: n_samples int64); rank r takes the slice `shard_range(n_samples, r, world)`.  A seeded
 single-process run and a sharded run therefore generate the same molecule sizes in the same order.
-Noise: per-rank device generator, seed `seed + rank`; bit-identity of the NOISE with an unsharded run
-is not promised (the reference draws it as one [B,N,*] tensor).
+Noise: per-rank device generator, seed `seed + rank` (with `seed=None` the base seed is drawn on rank 0 and
+broadcast - ranks never share a noise stream); bit-identity of the NOISE with an unsharded run is not promised
+(the reference draws it as one [B,N,*] tensor).
+Failure: a rank whose shard raises does not leave the others parked in the gather - one status byte per rank is
+exchanged first and EVERY rank raises `ShardError`.
 """
 from __future__ import annotations
 
@@ -94,6 +97,36 @@ def gather_results(local: Dict[str, torch.Tensor], n_samples: int, group=None) -
     return out
 
 
+class ShardError(RuntimeError):
+    """Raised on EVERY rank when the shard of at least one rank failed (a shard failure must
+    not leave the other ranks parked in the final collective)."""
+
+
+def draw_base_seed(group=None) -> int:
+    """A noise base seed that is identical on every rank: drawn on rank 0 from the CPU global RNG (after the size
+    draw, so the sizes stay what a single-process run draws) and broadcast."""
+    world, rank = world_and_rank(group)
+    if world == 1:
+        return int(torch.randint(0, 2 ** 31 - 1, (1,)))
+    dev = _collective_device(group)
+    t = torch.randint(0, 2 ** 31 - 1, (1,)).to(dev) if rank == 0 else torch.zeros(1, dtype=torch.long, device=dev)
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast(t, src=src, group=group)
+    return int(t.item())
+
+
+def exchange_status(ok: bool, group=None) -> List[bool]:
+    """One byte per rank, all-gathered BEFORE the result tensors: which ranks finished their shard."""
+    world, _ = world_and_rank(group)
+    if world == 1:
+        return [ok]
+    dev = _collective_device(group)
+    mine = torch.tensor([1 if ok else 0], dtype=torch.uint8, device=dev)
+    buf = torch.empty(world, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(buf, mine, group=group)
+    return [bool(v) for v in buf.cpu().tolist()]
+
+
 def sharded_generate(n_samples: int, draw_sizes: Callable[[], torch.Tensor],
                      run_shard: Callable[[torch.Tensor, int, int], Dict[str, torch.Tensor]], group=None,
                      seed: Optional[int] = None, seed_fn: Optional[Callable[[int], None]] = None
@@ -103,8 +136,12 @@ def sharded_generate(n_samples: int, draw_sizes: Callable[[], torch.Tensor],
 
       sizes  = draw_sizes() once for the whole batch (identical on every rank, see `draw_global_sizes`)
       lo, hi = shard_range(n_samples, rank, world)
-      seed_fn(rank_seed(seed, rank))            # per-rank noise stream, when a seed is given
+      seed_fn(rank_seed(seed, rank))            # per-rank noise stream - ALWAYS when world > 1: with `seed` None the
+                                                # base seed is drawn on rank 0 and broadcast (`draw_base_seed`); every
+                                                # process starts its device generator from the same constant, so
+                                                # "leave the generators alone" would make all shards identical
       local  = run_shard(sizes[lo:hi], lo, hi)  # dict of per-sample tensors, dim 0 = hi - lo (may be 0)
+      status = exchange_status(...)             # one byte per rank; ShardError on EVERY rank if any shard failed
       full   = gather_results(local)            # the ONLY data-path collective, at the very end
 
     Returns (sizes, full) on every rank; `full` is in sample order."""
@@ -113,10 +150,26 @@ def sharded_generate(n_samples: int, draw_sizes: Callable[[], torch.Tensor],
     if sizes.numel() != n_samples:
         raise ValueError(f"draw_sizes() returned {sizes.numel()} sizes for n_samples={n_samples}")
     lo, hi = shard_range(n_samples, rank, world)
-    if seed is not None and seed_fn is not None:
-        seed_fn(rank_seed(seed, rank))
-    local = run_shard(sizes[lo:hi], lo, hi)
-    for key, t in local.items():
-        if t.shape[0] != hi - lo:
-            raise ValueError(f"run_shard returned {t.shape[0]} rows of `{key}` for a shard of {hi - lo}")
+    if seed_fn is not None:
+        if seed is None and world > 1:
+            seed = draw_base_seed(group)
+        if seed is not None:
+            seed_fn(rank_seed(seed, rank))
+    local, failure = None, None
+    try:
+        local = run_shard(sizes[lo:hi], lo, hi)
+        for key, t in local.items():
+            if t.shape[0] != hi - lo:
+                raise ValueError(f"run_shard returned {t.shape[0]} rows of `{key}` for a shard of {hi - lo}")
+    except Exception as e:  # noqa: BLE001 - reported to every rank below, then re-raised
+        if world == 1:
+            raise
+        failure = e
+    status = exchange_status(failure is None, group)
+    if not all(status):
+        bad = [r for r, ok in enumerate(status) if not ok]
+        msg = f"shard generation failed on rank(s) {bad} of {world}"
+        if failure is not None:
+            raise ShardError(f"{msg}; this rank ({rank}): {type(failure).__name__}: {failure}") from failure
+        raise ShardError(msg + f"; this rank ({rank}) finished its shard")
     return sizes, gather_results(local, n_samples, group)

@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from ml_conformer_generator_amd.distributed import (draw_global_sizes, gather_results, rank_seed, shard_range,
+from ml_conformer_generator_amd.distributed import (ShardError, draw_global_sizes, gather_results, rank_seed, shard_range,
                                                     shard_sizes, sharded_generate)
 
 
@@ -77,7 +77,7 @@ def _shell_generator():
     gen.device = torch.device("cpu")
     gen.dimension = 42
     gen.min_n_nodes, gen.max_n_nodes = 15, 39
-    gen.last_batch = gen.last_valid_fraction = gen._timing = None
+    gen.last_batch = gen.last_valid_fraction = gen._timing = gen.last_noise_seed = None
     return gen
 
 
@@ -118,6 +118,10 @@ def _shard_worker(rank, world, port, n_samples, q):
     _, full = sharded_generate(1, lambda: draw_global_sizes(1, 20, 20), lambda sz, lo_, hi_: {"v": sz.float()},
                                seed=7, seed_fn=seeds.append)
     ok = ok and seeds == [rank_seed(7, rank)] and full["v"].tolist() == [20.0]
+    # DEFAULT arguments (seed=None): the ranks must still draw DIFFERENT noise - base seed from rank 0 + rank
+    seen = [None] * world
+    dist.all_gather_object(seen, gen.last_noise_seed)
+    ok = ok and None not in seen and seen[1] == seen[0] + 1
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
@@ -134,6 +138,46 @@ def test_generate_conformers_sharded_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _failing_worker(rank, world, port, q):
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gen = _shell_generator()
+    good = _stub_shard([])
+
+    def shard(*a):
+        if rank == 1:
+            raise RuntimeError("device fault injected on rank 1")
+        return good(*a)
+    gen._generate_shard = shard
+    t0 = time.time()
+    try:
+        gen.generate_conformers_sharded(reference_context=torch.tensor([50.0, 100.0, 130.0]), n_atoms=27, variance=2,
+                                        n_samples=6)
+        res = "returned"
+    except ShardError as e:
+        res = ("ShardError", "rank(s) [1]" in str(e), ("injected" in str(e)) == (rank == 1))
+    q.put((rank, res, time.time() - t0 < 30.0))
+    dist.barrier()                       # the group is still usable: nobody is parked in a half-done collective
+    dist.destroy_process_group()
+
+
+def test_failing_shard_raises_on_every_rank_world2_gloo():
+    """a rank whose shard raises must not leave the others waiting in the final gather until
+    the collective times out - every rank raises ShardError within seconds."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, ("ShardError", True, True), True), (1, ("ShardError", True, True), True)]
 
 
 def test_sharded_path_without_a_process_group_is_the_plain_call():
