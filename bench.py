@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="also time one denoiser call at B/8 with torch.set_num_threads(os.cpu_count()) (BASELINE.md section 3's "
                          "rule; ~80 s on the 256-core GPU box, where it is 229x slower than 16 threads)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32x6", "f32x9"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32x6"],
                     help="bf16 = opt-in reduced-precision MFMA operands (configs[4]); the default bench line is fp32")
     ap.add_argument("--no-config2", action="store_true",
                     help="skip the second object of the default line (BASELINE configs[2] shape: 256 ragged molecules)")
@@ -356,19 +356,49 @@ def x6_probe(args, gen, sd, gsd, ctx, dev):
                     "accumulates in fp32; passes the same fp32 parity tolerance as the exact kernel (DESIGN.md)"}
 
 
+def time_edge_kernel_in_call(gen, plan, dev, calls=3):
+    """Mean duration of the GCL edge kernel INSIDE whole denoiser calls: the kernel's own begin / end timestamps
+    (hipExtLaunchKernelGGL events on the launching stream, `mcg_bench_edge_incall`), 18 launches per call behind and in
+    front of the node GEMMs - the context the sampler runs it in, and the figure a rocprofv3 kernel trace of the timed
+    region reports.  (Back-to-back launches of this one kernel for milliseconds draw more power than the sampler's mix and
+    run 1-10 % slower on some boxes: reported beside it as `standalone_*`.)"""
+    import numpy as np
+    from ml_conformer_generator_amd import _lib
+    L = _lib.lib()
+    dyn = gen.generative_model.dynamics
+    B, N = plan.B, plan.N
+    nm = plan.node_mask()
+    g = torch.Generator(device=dev).manual_seed(5)
+    xh = torch.randn(B, N, 11, device=dev, generator=g) * nm
+    ctx = torch.tensor([-0.99, -1.66, -1.66], device=dev).view(1, 1, 3).repeat(B, N, 1) * nm
+    t = torch.full((B,), 0.5, device=dev)
+    out = torch.empty_like(xh)
+    us = np.zeros(4, dtype=np.float32)
+    stream = _lib.current_stream_ptr(dev)
+    for n_calls in (1, calls):            # one untimed-for-the-result warm call, then the measured ones
+        _lib.check(L.mcg_bench_edge_incall(dyn.handle, plan.handle, _lib.dptr(t), _lib.dptr(xh), _lib.dptr(ctx), _lib.dptr(out),
+                                           n_calls, us.ctypes.data, stream), "mcg_bench_edge_incall")
+    return float(us[0]) * 1e-6, float(us[1]) * 1e-6, int(us[2])
+
+
 def edge_roofline(args, gen, dev, dtype, traffic=None, traffic_source=None):
     plan = next(reversed(gen.generative_model.dynamics._plans.values()))
-    edge_s, edge_best = time_edge_kernel(gen, plan, dev)
+    sa_mean, sa_best = time_edge_kernel(gen, plan, dev)
+    edge_s, equiv_s, n_timed = time_edge_kernel_in_call(gen, plan, dev)
     fl = edge_flops_per_launch(plan.n_real_edges)
-    if dtype in ("f32x6", "f32x9"):
-        fl *= 6.0 if dtype == "f32x6" else 9.0          # executed bf16 FLOPs: six partial products per fp32 product (K padded 420 -> 448 not counted)
+    if dtype == "f32x6":
+        fl *= 6.0          # executed bf16 FLOPs: six partial products per fp32 product (K padded 420 -> 448 not counted)
     achieved = fl / edge_s / 1e12
     peak_tf = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else 2500.0      # dense bf16 MFMA peak
     return plan, {"kernel": "k_edge (fused edge MLP: layer-1 finish + 420x420 MFMA + gate + per-node sum)",
                   "bound": "mfma", "achieved": achieved, "peak": peak_tf, "unit": "TFLOP/s",
                   "frac": achieved / peak_tf, "traffic": traffic, "traffic_source": traffic_source,
-                  "avg_launch_us": edge_s * 1e6, "best_launch_us": edge_best * 1e6,
-                  "launch_timing": "HIP events on the launching stream, 3 batches of 20 back-to-back launches: mean / best batch",
+                  "avg_launch_us": edge_s * 1e6, "launches_timed": n_timed,
+                  "launch_timing": "mean of the GCL edge launches of 3 whole denoiser calls, each launch's own begin / end "
+                                   "timestamps (hipExtLaunchKernelGGL events on the launching stream)",
+                  "coordinate_variant_avg_launch_us": equiv_s * 1e6,
+                  "standalone_avg_launch_us": sa_mean * 1e6, "standalone_best_launch_us": sa_best * 1e6,
+                  "standalone_timing": "HIP events around 3 batches of 20 back-to-back launches of this kernel alone: mean / best batch",
                   "flops_per_launch": fl}
 
 
@@ -583,9 +613,7 @@ def main():
         mode_text = {"f32": "fp32 HIP EGNN + GCN",
                      "bf16": "bf16-operand MFMA HIP EGNN (fp32 accumulate/state) + fp32 GCN",
                      "f32x6": "fp32 HIP EGNN with the edge-MLP contraction as 6 bf16 partial products of "
-                              "3-part fp32 operands (fp32-accurate, fp32 accumulate) + fp32 GCN",
-                     "f32x9": "fp32 HIP EGNN with the edge-MLP contraction as all 9 bf16 partial products of "
-                              "3-part fp32 operands (exact products, fp32 accumulate) + fp32 GCN"}[args.dtype]
+                              "3-part fp32 operands (fp32-accurate, fp32 accumulate) + fp32 GCN"}[args.dtype]
         out = {
             "metric": f"valid molecules/sec @{args.diffusion_steps} diffusion steps (`value` = RAW molecules/s through the whole "
                       "public path: the reference's validity gate needs RDKit + trained weights, unavailable offline; see `validity`)",

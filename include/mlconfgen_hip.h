@@ -6,27 +6,16 @@
  * replaces.  Plain pointers and sizes only; every float buffer is fp32, row-major, contiguous and
  * lives in DEVICE memory unless the name ends in `_host`.  `stream` is a hipStream_t (0 = default).
  * All functions return 0 on success (MCG_OK) or a non-zero code; mcg_last_error() gives the text.
- * No global mutable state except the opaque handles and the process-wide measurement switches below, which are
- * read from the environment (MCG_GRAPH, MCG_X6_GEMM, MCG_WG_SUMS and MCG_NS_MAX_TILES once, on first use, and then cached for the
- * life of the process; the others at every plan creation / launch) - none is needed for normal operation:
- *   MCG_GRAPH=0          plain launches instead of the captured HIP graph per denoiser call
- *   MCG_NS_MAX_TILES=n   largest batch (16-row edge tiles) that takes the stand-alone column-split edge kernel when a
- *                        plan has no workgroup-level tables (512)
- *   MCG_TAIL=0|n|-1      four-tile workgroups of the throughput edge kernel: all / the first n / none (default: every
- *                        complete round of the chip), read at plan creation
- *   MCG_EDGE_MT=1|2      rows/16 per wave of the exact-fp32 edge kernel for new plans
- *   MCG_SPLIT=n          molecule ranges (HIP streams) per plan, overriding the library's choice
- *   MCG_WG_SUMS=0        per-wave partial sums + combine / coordinate-update launches instead of the workgroup-level
- *                        sums of the exact-fp32 throughput edge kernel (read once, cached)
- *   MCG_SPLIT_FRAC=f     with MCG_SPLIT=2: share of the edge rows given to the first range
- *   MCG_GEMM_RN=1..3, MCG_GEMM_X6_RN=1..3   wave tile width of the node GEMMs
- *   MCG_X6_GEMM=0        f32x6 / f32x9 modes: node GEMMs on the exact fp32 kernel
- *   MCG_VERBOSE=1        graph capture diagnostics on stderr
+ * No global mutable state except the opaque handles.  Behaviour is chosen through arguments: `mcg_plan_opts`
+ * (per plan), `mcg_egnn_set_precision` / `mcg_egnn_set_option` (per model), `mcg_plan_set_latency_mode`.  Two PROCESS
+ * switches remain, read from the environment, neither needed for normal operation:
+ *   MCG_GRAPH=0     plain launches instead of the captured HIP graph per denoiser call (read once, on first use)
+ *   MCG_VERBOSE=1   graph capture diagnostics on stderr
  * (Python side: MCG_LIB_PATH = alternative library file, MCG_FORCE_COLLECTIVE=1 = run the final gather on a 1-rank
- * group.)  Threading: like the reference (single Python thread, one
- * stream) - a handle carries workspace, so one mcg_plan / mcg_gcn must not run on two host threads or two streams at
- * once; different handles are independent, mcg_egnn weights are read-only after creation (mcg_egnn_set_precision
- * excepted) and may be shared by several plans.  mcg_last_error() is thread-local.
+ * group.)  Threading: like the reference (single Python thread, one stream) - a handle carries workspace, so one
+ * mcg_plan / mcg_gcn must not run on two host threads or two streams at once; different handles are independent,
+ * mcg_egnn weights are read-only after creation (mcg_egnn_set_precision / mcg_egnn_set_option excepted) and may be
+ * shared by several plans.  mcg_last_error() is thread-local.
  */
 #ifndef MLCONFGEN_HIP_H
 #define MLCONFGEN_HIP_H
@@ -60,30 +49,50 @@ void mcg_egnn_destroy(mcg_egnn* m);
  * mode 2 "f32x6": fp32-accurate edge-MLP contraction on the bf16 matrix pipe: each fp32 operand is carried as the
  *                 exact sum of three bf16 parts and the six partial products of weight >= 2^-16 are accumulated
  *                 in fp32 (dropped terms <= 2^-23 relative); everything else as mode 0.  Uses edge_mt = 4 plans
- *                 (other plans run the exact kernels).
- * mode 3 "f32x9": as mode 2 with all nine partial products (every fp32 product formed exactly). */
+ *                 (other plans run the exact kernels). */
 int mcg_egnn_set_precision(mcg_egnn* m, int mode);
+/* Model-level measurement options (defaults in brackets; none is needed for normal operation):
+ *   MCG_OPT_X6_GEMM     [1]  f32x6 mode: 1 = node-side GEMMs on the split-operand kernel too, 0 = exact fp32 GEMMs
+ *   MCG_OPT_GEMM_RN     [0]  wave tile width (column tiles) of the 32-row node GEMM kernel: 0 = cost model, 1..3
+ *   MCG_OPT_GEMM_X6_RN  [0]  same for the split-operand GEMM kernel */
+enum { MCG_OPT_X6_GEMM = 1, MCG_OPT_GEMM_RN = 2, MCG_OPT_GEMM_X6_RN = 3 };
+int mcg_egnn_set_option(mcg_egnn* m, int option, int value);
 
 /* ---- Batch plan.  Replaces the per-call `get_adj_matrix` edge-list rebuild (egnn.py:475,515-541)
  * and the node/edge masks (mol_utils.py:226-252): node_mask[b] is the prefix of n_nodes_host[b]
- * ones, edge_mask = outer product minus diagonal.  edge_mt: 0 = auto, 1..2 = rows/16 per wave. */
+ * ones, edge_mask = outer product minus diagonal.  edge_mt: 0 = auto, 1 = 16-row edge tiles (exact-fp32 kernels,
+ * 16-row bf16 kernel), 4 = 64-row units (bf16 / f32x6 kernels; needs <= 16 atoms' rows per unit). */
 int mcg_plan_create(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_plan** out);
-/* Same, with the number of independent molecule ranges (each runs the whole denoiser on its own HIP stream inside
- * mcg_egnn_dynamics; 0 = the library's choice: for 16-row-tile plans 1 / 2 / 3 / 4 ranges below 3 600 / 5 200 / 14 000 /
- * from 14 000 edge tiles on, for 64-row-unit plans 2 from 8 192 tiles on) given by the caller. */
-int mcg_plan_create_ranges(int B, int N, const int32_t* n_nodes_host, int edge_mt, int n_ranges, mcg_plan** out);
+/* The same with every choice the library would make itself open to the caller (a zero-initialised struct = defaults;
+ * `opts` may be NULL):
+ *   edge_mt          as above
+ *   n_ranges         independent molecule ranges, each running the whole denoiser on its own HIP stream inside
+ *                    mcg_egnn_dynamics: 0 = the library's choice (16-row-tile plans: 1 / 2 / 3 / 4 ranges below 3 600 /
+ *                    5 200 / 14 000 / from 14 000 edge tiles on; 64-row-unit plans: 2 from 8 192 tiles on), 1..4 given
+ *   four_tile_units  workgroups of the exact-fp32 throughput edge kernel that take four 16-row tiles each (the rest take
+ *                    ONE tile, its columns split over the 4 waves): 0 = every complete round of the chip (default),
+ *                    -1 = none, n > 0 = the first n (rounded up to a multiple of 8, capped at all of them;
+ *                    MCG_ALL_FOUR_TILE = all) */
+typedef struct mcg_plan_opts {
+    int32_t edge_mt;
+    int32_t n_ranges;
+    int32_t four_tile_units;
+    int32_t reserved[5];          /* must be zero */
+} mcg_plan_opts;
+#define MCG_ALL_FOUR_TILE 0x3fffffff
+int mcg_plan_create_ex(int B, int N, const int32_t* n_nodes_host, const mcg_plan_opts* opts, mcg_plan** out);
 void mcg_plan_destroy(mcg_plan* p);
 /* Edge-kernel choice (exact-fp32 mode, edge_mt 1): -1 auto - the throughput kernel, whose workgroups take four 16-row
  * tiles each for every complete round of the chip and ONE tile each (columns split over the 4 waves) for the rest, i.e.
  * for the whole of a small batch; 0 = four-tile workgroups only; 1 = the stand-alone column-split kernel with per-wave
  * partial sums (the fallback for plans without workgroup-level tables). */
 int mcg_plan_set_latency_mode(mcg_plan* p, int mode);
-/* Host-only self-check of the tables mcg_plan_create would build for a device with `cus` compute units (no GPU call;
- * honours MCG_TAIL / MCG_EDGE_MT like mcg_plan_create): every edge row's (unit, tile, segment) must land in a slot its
+/* Host-only self-check of the tables mcg_plan_create_ex would build for a device with `cus` compute units (no GPU
+ * call; same `opts`): every edge row's (unit, tile, segment) must land in a slot its
  * atom lists, no slot may be shared by two atoms, a four-tile unit parks <= 16 rows, the row table names the right
  * (i, j).  info[8] = {table sets, units, four-tile units, slots, most slots per atom of set 0; units, slots, most slots
  * per atom of set 1 (four-tile units only; zeros when there is one set)}.  Returns MCG_OK or an error with text. */
-int mcg_plan_check_tables(int B, int N, const int32_t* n_nodes_host, int edge_mt, int cus, int32_t* info_host);
+int mcg_plan_check_tables(int B, int N, const int32_t* n_nodes_host, const mcg_plan_opts* opts, int cus, int32_t* info_host);
 /* info[8] = {real nodes, real edges, edge_mt, edge waves, partial slots, B, N, 16-row edge tiles} */
 int mcg_plan_info(const mcg_plan* p, int32_t* info_host);
 
@@ -108,6 +117,12 @@ int mcg_plan_peek(const mcg_plan* p, int which, float* dst, void* stream);
 /* Measurement hook: the edge-MLP kernel of GCL layer `layer` (equiv = 0, 0..2*n_blocks-1) or of the
  * coordinate update of block `layer` (equiv = 1) launched `iters` times on the plan's current state. */
 int mcg_bench_edge(const mcg_egnn* m, mcg_plan* p, int layer, int equiv, int iters, void* stream);
+/* Measurement hook: `calls` whole denoiser calls (arguments as mcg_egnn_dynamics) issued as plain launches with every
+ * edge-MLP launch bracketed by events that receive the kernel's own begin / end timestamps, i.e. the dominant kernel timed
+ * in the context it runs in.  us_host[4] = {mean us of the 18 GCL edge launches per call, mean us of the 9 coordinate-layer
+ * ones, how many of each were timed}.  Synchronises `stream`. */
+int mcg_bench_edge_incall(const mcg_egnn* m, mcg_plan* p, const float* t, const float* xh, const float* context, float* out,
+                          int calls, float* us_host, void* stream);
 
 /* ---- Sampler arithmetic (equivariant_diffusion.py).  randn_x[B,N,3] / randn_h[B,N,8] are RAW
  * standard-normal draws (the caller draws them in the reference's order: x first, then h);

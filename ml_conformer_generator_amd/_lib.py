@@ -23,17 +23,19 @@ SIGNATURES: Dict[str, tuple] = {
     "mcg_egnn_create": (_i, [_pp, _i, _i, _i, _pp]),
     "mcg_egnn_destroy": (None, [_vp]),
     "mcg_egnn_set_precision": (_i, [_vp, _i]),
+    "mcg_egnn_set_option": (_i, [_vp, _i, _i]),
     "mcg_plan_create": (_i, [_i, _i, _vp, _i, _pp]),
-    "mcg_plan_create_ranges": (_i, [_i, _i, _vp, _i, _i, _pp]),
+    "mcg_plan_create_ex": (_i, [_i, _i, _vp, _vp, _pp]),
     "mcg_plan_destroy": (None, [_vp]),
     "mcg_plan_info": (_i, [_vp, _vp]),
     "mcg_plan_set_latency_mode": (_i, [_vp, _i]),
-    "mcg_plan_check_tables": (_i, [_i, _i, _vp, _i, _i, _vp]),
+    "mcg_plan_check_tables": (_i, [_i, _i, _vp, _vp, _i, _vp]),
     "mcg_egnn_dynamics": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mcg_egnn_block_debug": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "mcg_egnn_gcl_debug": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "mcg_plan_peek": (_i, [_vp, _i, _vp, _vp]),
     "mcg_bench_edge": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "mcg_bench_edge_incall": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "mcg_sampler_noise": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mcg_sampler_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp]),
     "mcg_sampler_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
@@ -48,6 +50,16 @@ SIGNATURES: Dict[str, tuple] = {
     "mcg_bond_writeback": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "mcg_ifm_merge": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
 }
+
+
+
+class PlanOpts(C.Structure):
+    """`mcg_plan_opts` (include/mlconfgen_hip.h): zero-initialised = the library's defaults."""
+    _fields_ = [("edge_mt", C.c_int32), ("n_ranges", C.c_int32), ("four_tile_units", C.c_int32), ("reserved", C.c_int32 * 5)]
+
+
+ALL_FOUR_TILE = 0x3fffffff          # MCG_ALL_FOUR_TILE
+OPT_X6_GEMM, OPT_GEMM_RN, OPT_GEMM_X6_RN = 1, 2, 3
 
 _lib = None
 

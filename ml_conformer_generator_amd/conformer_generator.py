@@ -5,15 +5,20 @@ Same constructor kwargs, method names, argument order and errors as
 forced by the scope of this build:
   * `device` must be a ROCm GPU (default cuda:0): there is no CPU path;
   * `edm_weights` / `adj_mat_seer_weights` may also be an in-memory state dict;
-  * the RDKit-owned stages are replaced by the native hand-off of `handoff.py` (two HIP
-    launches) and results are `GeneratedMolecule` records instead of `Chem.Mol`
-    (`.to_molblock()` feeds them to RDKit where it exists; an RDKit Mol is still accepted
-    as the reference conformer / fixed fragment);
+  * the RDKit-owned stages BEFORE the GCN are replaced by the native hand-off of `handoff.py`
+    (two HIP launches);
+  * RETURN TYPE: where RDKit imports, `generate_conformers` returns `List[Chem.Mol]` like the
+    reference - the HIP path's molecules go through `rdkit_finish.finish` (the reference's
+    `standardize_mol` sequence incl. MMFF when `optimise_geometry`; untested offline, RDKit is
+    absent here); without RDKit it returns `GeneratedMolecule` records filtered by the labelled
+    valence / single-fragment PROXY, and `optimise_geometry=True` cannot be honoured (one
+    warning per process).  An RDKit Mol is accepted as reference conformer / fixed fragment;
   * `generate_conformers_sharded(...)`: the same call, batch-sharded over the ranks of an
     initialised `torch.distributed` group (one process per GPU, one gather at the end).
 """
 from __future__ import annotations
 
+import warnings
 from typing import List, Optional, Union
 
 import torch
@@ -37,6 +42,27 @@ try:  # RDKit is optional on this path
 except Exception:  # noqa: BLE001
     Chem = None
     HAVE_RDKIT = False
+
+
+_WARNED_NO_MMFF = [False]
+
+
+def _finish(mols: List, optimise_geometry: bool):
+    """(returned list, valid fraction): the reference's RDKit gate where RDKit exists, else the proxy filter."""
+    if not mols:
+        return [], 0.0
+    if HAVE_RDKIT:
+        from . import rdkit_finish
+        done = rdkit_finish.finish(mols, optimise_geometry)
+        kept = [m for m in done if m is not None]
+        return kept, len(kept) / len(mols)
+    if optimise_geometry and not _WARNED_NO_MMFF[0]:
+        _WARNED_NO_MMFF[0] = True
+        warnings.warn("ml_conformer_generator_amd: RDKit is not installed - optimise_geometry=True (MMFF94) is NOT applied and "
+                      "validity is the labelled valence / single-fragment proxy; pass optimise_geometry=False to silence this",
+                      RuntimeWarning, stacklevel=3)
+    kept = [m for m in mols if m.valid]
+    return kept, len(kept) / len(mols)
 
 
 def _load_state_dict(src, device) -> dict:
@@ -205,15 +231,15 @@ class MLConformerGenerator(torch.nn.Module):
                             inertial_fragment_matching: bool = True, blend_power: int = 3,
                             ifm_diffusion_level: int = 50) -> List:
         """Generate molecules from a reference shape (conformer_generator.py:268-368).
-        Returns the VALID molecules only (invalid ones are dropped, as in the reference); without RDKit
-        "valid" is the labelled valence / single-fragment proxy of `mcg_bond_writeback`.
-        `optimise_geometry` is accepted for signature parity: MMFF is RDKit's and does not run here."""
+        Returns the VALID molecules only (invalid ones are dropped, as in the reference): `List[Chem.Mol]` through the
+        reference's standardisation (+ MMFF94 when `optimise_geometry`) where RDKit imports, else `GeneratedMolecule`
+        records that pass the labelled valence / single-fragment proxy of `mcg_bond_writeback` (no MMFF: warned once)."""
         ref_context, ref_n_atoms = self._reference_context(reference_conformer, reference_context, n_atoms)
         res = self._generate_shard(ref_context, ref_n_atoms, variance, None, n_samples, resample_steps, fixed_fragment,
                                    inertial_fragment_matching, blend_power, ifm_diffusion_level)
         mols = molecules_from_tensors(res["x"], res["elements"], res["bond"], res["n_nodes"], res["valid"])   # single D2H
-        self.last_valid_fraction = (sum(m.valid for m in mols) / len(mols)) if mols else 0.0
-        return [m for m in mols if m.valid]
+        kept, self.last_valid_fraction = _finish(mols, optimise_geometry)
+        return kept
 
     @torch.no_grad()
     def generate_conformers_sharded(self, reference_conformer=None, n_samples: int = 10, variance: int = 2,
@@ -247,8 +273,8 @@ class MLConformerGenerator(torch.nn.Module):
             n_samples, lambda: mcg_dist.draw_global_sizes(n_samples, lo_n, hi_n, group), run_shard, group=group,
             seed=seed, seed_fn=seed_device)
         mols = molecules_from_tensors(res["x"], res["elements"], res["bond"], res["n_nodes"], res["valid"])
-        self.last_valid_fraction = (sum(m.valid for m in mols) / len(mols)) if mols else 0.0
-        return [m for m in mols if m.valid]
+        kept, self.last_valid_fraction = _finish(mols, optimise_geometry)
+        return kept
 
     @torch.no_grad()
     def forward(self, reference_conformer=None, n_samples: int = 10, variance: int = 2,

@@ -5,10 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
-#define MCG_OK 0
-#define MCG_ERR_ARG 1
-#define MCG_ERR_HIP 2
-#define MCG_ERR_STATE 3
+#include "mcg_error.h"
 
 #define MCG_HIP(call)                                                                       \
     do {                                                                                    \
@@ -18,8 +15,6 @@
             return MCG_ERR_HIP;                                                             \
         }                                                                                   \
     } while (0)
-
-extern "C" void mcg_set_error(const char* fmt, ...);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

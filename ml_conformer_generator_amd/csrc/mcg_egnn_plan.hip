@@ -1,0 +1,206 @@
+// Device half of a batch plan (mcg_plan): uploads the host tables of mcg_plan_host.cpp, allocates the workspace that all
+// 101 denoiser calls of a sampling run reuse, and optionally cuts the batch into molecule ranges on separate HIP streams.
+#include "mcg_egnn_internal.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace { constexpr int HP = MCG_HP; }
+
+int mcg_plan_B(const mcg_plan* p) { return p->B; }
+int mcg_plan_N(const mcg_plan* p) { return p->N; }
+const int* mcg_plan_n_nodes(const mcg_plan* p) { return p->n_nodes; }
+
+static int plan_create_single(int B, int N, const int32_t* n_nodes_host, const mcg_plan_opts* opts, mcg_plan** out) {
+    if (B < 1 || N < 1 || !n_nodes_host || !out) {
+        mcg_set_error("mcg_plan_create: bad arguments");
+        return MCG_ERR_ARG;
+    }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipGetLastError();
+    McgPlanHost H;
+    if (int e = mcg_plan_build_host(B, N, n_nodes_host, opts, cus, H)) return e;
+    mcg_plan* p = new mcg_plan();
+    p->B = H.B; p->N = H.N; p->M = H.M; p->n_rows = H.n_rows; p->n_mtiles = H.n_mtiles; p->MT = H.MT; p->n_waves = H.n_waves;
+    p->n_pslots = H.n_pslots; p->wgc = H.wgc;
+    std::vector<int>&nn = H.nn, &node_off = H.node_off, &node_mol = H.node_mol, &wave_poff = H.wave_poff, &ij = H.ij,
+                    &node_slots = H.node_slots;
+    McgPlanHost::Set (&ht)[2] = H.ht;
+    const int n_sets = H.n_sets, best = H.MT, R = 16 * H.MT;
+    const bool slots_ok = H.slots_ok, segs_ok = H.segs_ok;
+    if (!segs_ok) {
+        mcg_set_error("mcg_plan_create: edge_mt = %d puts more than 16 atoms' rows into one %d-row unit (molecules this "
+                      "small need edge_mt = 1)", best, R);
+        delete p;
+        return MCG_ERR_ARG;
+    }
+    int e = 0;
+    {
+        int* d = nullptr;
+        e |= mcg_upload_i(ij, &d);
+        p->row_ij = reinterpret_cast<int2*>(d);
+        p->allocs.push_back(d);
+    }
+    if (!slots_ok) {
+        mcg_set_error("mcg_plan_create: a molecule's edge rows span more than 8 tiles per atom (N > 114 is not supported)");
+        mcg_plan_destroy(p);
+        return MCG_ERR_ARG;
+    }
+    e |= mcg_upload_i(node_slots, &p->node_slots);
+    p->allocs.push_back(p->node_slots);
+    e |= mcg_upload_i(nn, &p->n_nodes); e |= mcg_upload_i(node_off, &p->node_off); e |= mcg_upload_i(wave_poff, &p->wave_poff);
+    e |= mcg_upload_i(node_mol, &p->node_mol);
+    int max_uslots = 0;
+    for (int k = 0; k < n_sets; ++k) max_uslots = std::max(max_uslots, ht[k].n_uslots);
+    for (int k = 0; k < n_sets; ++k) {
+        for (int& v : ht[k].node_slots) if (v < 0) v = max_uslots;       // the zero row (never written) is common to both sets
+        int* d = nullptr;
+        int* wi = nullptr;
+        e |= mcg_upload_i(ht[k].wg_info, &wi); e |= mcg_upload_i(ht[k].node_slots, &d);
+        mcg_plan::UnitTables& T = p->ut[k];
+        T.wg_info = reinterpret_cast<int4*>(wi);
+        T.node_slots = reinterpret_cast<int4*>(d);
+        T.n_units = ht[k].n_units; T.n_full_wg = ht[k].n_full; T.n_uslots = ht[k].n_uslots; T.max_span = ht[k].span;
+        p->allocs.insert(p->allocs.end(), {(void*)wi, (void*)d});
+    }
+    p->have_alt = n_sets == 2;
+    if (e) { mcg_plan_destroy(p); return MCG_ERR_HIP; }
+    p->allocs.insert(p->allocs.end(), {(void*)p->n_nodes, (void*)p->node_off, (void*)p->wave_poff, (void*)p->node_mol});
+    const size_t M1 = (size_t)(p->M > 0 ? p->M : 1);
+    struct { float** ptr; size_t n; } bufs[] = {
+        // (+64 floats: the bf16 kernels read activation rows up to k = 447, i.e. 16 floats past the last row)
+        {&p->x, M1 * 4}, {&p->x0, M1 * 4}, {&p->h, M1 * HP + 64}, {&p->h2, M1 * HP + 64}, {&p->pab, M1 * 2 * HP + 64},
+        {&p->agg, M1 * HP + 64}, {&p->t1, M1 * HP + 64}, {&p->P, (size_t)(p->n_pslots + 1) * HP}, {&p->Px, (size_t)(p->n_pslots + 1) * 4},
+        {&p->U, (size_t)(max_uslots + 1) * HP + 64}, {&p->Ux, (size_t)(max_uslots + 1) * 4}};
+    for (auto& b : bufs) {
+        if (hipMalloc((void**)b.ptr, b.n * sizeof(float)) != hipSuccess || hipMemset(*b.ptr, 0, b.n * sizeof(float)) != hipSuccess) {
+            mcg_set_error("mcg_plan_create: out of device memory (%zu floats)", b.n);
+            (void)hipGetLastError();
+            if (*b.ptr) p->allocs.push_back(*b.ptr);
+            mcg_plan_destroy(p);
+            return MCG_ERR_HIP;
+        }
+        p->allocs.push_back(*b.ptr);
+    }
+    *out = p;
+    return MCG_OK;
+}
+
+extern "C" {
+
+void mcg_plan_destroy(mcg_plan* p) {
+    if (!p) return;
+    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+    if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
+    for (mcg_plan* q : p->subs) mcg_plan_destroy(q);
+    for (hipStream_t st : p->streams) (void)hipStreamDestroy(st);
+    for (hipEvent_t e : p->ev_join) (void)hipEventDestroy(e);
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    for (void* q : p->allocs) (void)hipFree(q);
+    delete p;
+}
+
+static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, const mcg_plan_opts* opts);
+
+int mcg_plan_create(int B, int N, const int32_t* n_nodes_host, int edge_mt, mcg_plan** out) {
+    mcg_plan_opts o{};
+    o.edge_mt = edge_mt;
+    return mcg_plan_create_ex(B, N, n_nodes_host, &o, out);
+}
+
+int mcg_plan_create_ex(int B, int N, const int32_t* n_nodes_host, const mcg_plan_opts* opts, mcg_plan** out) {
+    const int n_ranges = opts ? opts->n_ranges : 0;
+    if (n_ranges < 0 || n_ranges > 4) { mcg_set_error("mcg_plan_create_ex: n_ranges must be 0 (auto) .. 4"); return MCG_ERR_ARG; }
+    if (opts)
+        for (int k = 0; k < 5; ++k)
+            if (opts->reserved[k] != 0) { mcg_set_error("mcg_plan_create_ex: mcg_plan_opts.reserved must be zero"); return MCG_ERR_ARG; }
+    mcg_plan* p = nullptr;
+    if (int e = plan_create_single(B, N, n_nodes_host, opts, &p)) return e;
+    if (int e = plan_finish(p, B, N, n_nodes_host, opts)) {
+        mcg_plan_destroy(p);          // streams, events, sub-plans and buffers created so far
+        return e;
+    }
+    *out = p;
+    return MCG_OK;
+}
+
+// graph staging buffer, capture stream and the optional split into molecule ranges
+static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, const mcg_plan_opts* opts) {
+    const int n_ranges = opts ? opts->n_ranges : 0;
+    MCG_HIP(hipMalloc((void**)&p->t_buf, (size_t)B * sizeof(float)));
+    p->allocs.push_back(p->t_buf);
+    MCG_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
+    // Split the batch into `parts` molecule ranges of ~equal edge count, one HIP stream each: the launch-bound node GEMMs
+    // of one range run under another range's edge kernel, and the ramps / tails of the edge kernels overlap.
+    // Exact-fp32 plans (16-row tiles), measured per denoiser call (tools/bench_kernels.py --ranges; W = workgroup-equivalents =
+    // tiles / 4, 27-atom molecules unless noted):  W = 702 (config 2): 4.54 / 4.96 / 4.93 ms with 1 / 2 / 3 ranges;
+    // 1 053: 6.85 / 6.42 / 6.83;  1 229: 7.93 / 7.55 / 7.60;  1 404: 8.79 / 8.84 / 8.49;  2 106: 13.01 / 12.94 / 12.66;
+    // 2 808: 16.92 / 17.12 / 16.05 (4: 16.72);  3 005 (config 3 shape, ragged): - / 17.37 / 17.11 (4: 18.0);
+    // 4 212: 3 ranges 24.99, 4: 23.94, 5: 26.7.  Hence the table below.  Other plans (64-row units of the bf16 / split-operand
+    // kernels) keep round 1's rule; the split-operand modes' host mirror asks for two ranges explicitly (f32x6 at
+    // config 2: 3.53 -> 3.18 ms per call - their edge kernel is short against the node phase).
+    int parts = 1;
+    if (n_ranges > 0) parts = n_ranges;
+    else if (p->MT == 1) parts = p->n_mtiles < 3600 ? 1 : p->n_mtiles < 5200 ? 2 : p->n_mtiles < 14000 ? 3 : 4;
+    else parts = p->n_mtiles >= 8192 ? 2 : 1;
+    if (parts < 2 || B < 2 * parts || p->n_rows < 4096) return MCG_OK;
+    std::vector<long> cum(B + 1, 0);
+    for (int b = 0; b < B; ++b) cum[b + 1] = cum[b] + (long)n_nodes_host[b] * (n_nodes_host[b] > 0 ? n_nodes_host[b] - 1 : 0);
+    int b0 = 0;
+    for (int k = 0; k < parts; ++k) {
+        int b1 = B;
+        if (k + 1 < parts) {
+            const long target = cum[B] * (k + 1) / parts;
+            b1 = b0 + 1;
+            while (b1 < B && cum[b1] < target) ++b1;
+        }
+        mcg_plan* sub = nullptr;
+        if (int e = plan_create_single(b1 - b0, N, n_nodes_host + b0, opts, &sub)) return e;
+        p->subs.push_back(sub);
+        p->sub_b0.push_back(b0);
+        hipStream_t st; hipEvent_t ev;
+        MCG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        MCG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        p->streams.push_back(st);
+        p->ev_join.push_back(ev);
+        b0 = b1;
+    }
+    MCG_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    return MCG_OK;
+}
+
+// mode: -1 auto, 0 four-tile units only, 1 the stand-alone column-split kernel
+int mcg_plan_set_latency_mode(mcg_plan* p, int mode) {
+    if (!p || mode < -1 || mode > 1) return MCG_ERR_ARG;
+    p->latency_mode = mode;
+    for (mcg_plan* q : p->subs) q->latency_mode = mode;
+    if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }   // re-capture
+    return MCG_OK;
+}
+
+int mcg_plan_info(const mcg_plan* p, int32_t* info /*[8]*/) {
+    if (!p || !info) return MCG_ERR_ARG;
+    info[0] = p->M; info[1] = p->n_rows; info[2] = p->MT; info[3] = p->n_waves; info[4] = p->n_pslots;
+    info[5] = p->B; info[6] = p->N; info[7] = p->n_mtiles;
+    return MCG_OK;
+}
+
+// Debug/test hook: copy one of the plan's internal buffers out.  which: 0 h[M][432], 1 pab[M][864], 2 agg[M][432],
+// 3 t1[M][432], 4 x[M][4]
+int mcg_plan_peek(const mcg_plan* pl, int which, float* dst, void* stream) {
+    if (!pl || !dst) return MCG_ERR_ARG;
+    const float* src = nullptr; size_t n = 0;
+    switch (which) {
+        case 0: src = pl->h; n = (size_t)pl->M * HP; break;
+        case 1: src = pl->pab; n = (size_t)pl->M * 2 * HP; break;
+        case 2: src = pl->agg; n = (size_t)pl->M * HP; break;
+        case 3: src = pl->t1; n = (size_t)pl->M * HP; break;
+        case 4: src = pl->x; n = (size_t)pl->M * 4; break;
+        default: return MCG_ERR_ARG;
+    }
+    MCG_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MCG_OK;
+}
+
+}  // extern "C"

@@ -425,12 +425,12 @@ __global__ __launch_bounds__(256) void mcg_gemm_x6_kernel(McgGemmArgs p) {
 }
 
 // launch of the f32x6 variant: Bp must point to a B-pack16x3
-static inline hipError_t mcg_gemm_x6_launch(const McgGemmArgs& a, hipStream_t s) {
+static inline hipError_t mcg_gemm_x6_launch(const McgGemmArgs& a, hipStream_t s, int rn_override = 0) {
     if (a.M <= 0) return hipSuccess;
     const int rowblocks = (a.M + 31) / 32;
     // 4 waves x RN tiles per workgroup: RN = 3 covers 12 tiles; pick the width that wastes the fewest wave slots
     int rn = a.M > 4096 ? 2 : 1;          // measured: RN = 1 at config 2 (3.43 vs 3.66 ms per call for RN = 3), RN = 2 at config 3
-    if (const char* e = getenv("MCG_GEMM_X6_RN")) { const int v = atoi(e); if (v >= 1 && v <= 3) rn = v; }
+    if (rn_override >= 1 && rn_override <= 3) rn = rn_override;          // mcg_egnn_set_option(MCG_OPT_GEMM_X6_RN)
     const int wave_cols = (a.n_tiles + rn - 1) / rn;
     dim3 grid((unsigned)(rowblocks * ((wave_cols + 3) / 4)));
     if (rn == 3) hipLaunchKernelGGL(mcg_gemm_x6_kernel<3>, grid, dim3(256), 0, s, a);
@@ -794,7 +794,7 @@ static inline hipError_t mcg_gemm16_launch(McgGemmArgs a, int rn, hipStream_t s,
     return hipGetLastError();
 }
 
-static inline hipError_t mcg_gemm_launch(const McgGemmArgs& a, hipStream_t s, bool bf16 = false) {
+static inline hipError_t mcg_gemm_launch(const McgGemmArgs& a, hipStream_t s, bool bf16 = false, int rn_override = 0) {
     if (a.M <= 0) return hipSuccess;
     const int rowblocks = (a.M + 31) / 32;
     // Wave tile width RN in {1,2,3} from a measured cost model (tools/native/gemm_bench.hip, MI355X; us of loop
@@ -823,7 +823,7 @@ static inline hipError_t mcg_gemm_launch(const McgGemmArgs& a, hipStream_t s, bo
             if (best < 0 || cost < best) { best = cost; rn = cand; }
         }
     }
-    if (const char* e = getenv("MCG_GEMM_RN")) { const int v = atoi(e); if (v >= 1 && v <= 3) rn = v; }
+    if (rn_override >= 1 && rn_override <= 3) rn = rn_override;          // mcg_egnn_set_option(MCG_OPT_GEMM_RN)
     const long waves = (long)rowblocks * ((a.n_tiles + rn - 1) / rn);
     dim3 grid((unsigned)((waves + 3) / 4));
     if (!bf16 && a.side_x) {                 // fp32 kernel only: coordinate-update side job behind the GEMM's workgroups

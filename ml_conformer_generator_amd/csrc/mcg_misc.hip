@@ -18,7 +18,7 @@ extern "C" void mcg_set_error(const char* fmt, ...) {
 
 extern "C" const char* mcg_last_error(void) { return g_err; }
 
-extern "C" int mcg_abi_version(void) { return 1; }
+extern "C" int mcg_abi_version(void) { return 2; }      // 2: mcg_plan_opts / mcg_plan_create_ex / mcg_egnn_set_option
 
 namespace {
 

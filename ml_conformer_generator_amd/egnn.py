@@ -22,7 +22,8 @@ class BatchPlan:
     Replaces the reference's per-call `get_adj_matrix` and mask tensors."""
 
     def __init__(self, n_nodes: torch.Tensor, max_n_nodes: int, device: torch.device, edge_mt: int = 0,
-                 n_ranges: int = 0):
+                 n_ranges: int = 0, four_tile_units: int = 0):
+        """`edge_mt`, `n_ranges`, `four_tile_units`: the fields of `mcg_plan_opts` (0 = the library's choice)."""
         L = _lib.lib()
         n_host = n_nodes.detach().to("cpu", torch.int32).contiguous().reshape(-1)
         self.B = int(n_host.numel())
@@ -30,9 +31,10 @@ class BatchPlan:
         self.device = torch.device(device)
         self.n_nodes_host = n_host
         self._h = C.c_void_p()
+        opts = _lib.PlanOpts(edge_mt=int(edge_mt), n_ranges=int(n_ranges), four_tile_units=int(four_tile_units))
         with torch.cuda.device(self.device):
-            _lib.check(L.mcg_plan_create_ranges(self.B, self.N, n_host.data_ptr(), int(edge_mt), int(n_ranges),
-                                                C.byref(self._h)), "mcg_plan_create_ranges")
+            _lib.check(L.mcg_plan_create_ex(self.B, self.N, n_host.data_ptr(), C.byref(opts), C.byref(self._h)),
+                       "mcg_plan_create_ex")
         info = torch.zeros(8, dtype=torch.int32)
         _lib.check(L.mcg_plan_info(self._h, info.data_ptr()), "mcg_plan_info")
         (self.n_real_nodes, self.n_real_edges, self.edge_mt, self.n_edge_waves, self.n_pslots, _, _,
@@ -124,30 +126,37 @@ class EGNNDynamics(torch.nn.Module):
         """"f32" (default): exact fp32 MFMA.  "bf16": MFMA operands rounded to bf16, fp32 accumulate,
         fp32 coordinates/aggregates/epilogues (BASELINE.json configs[4]).  "f32x6": fp32-accurate edge-MLP
         contraction as six bf16 partial products of three-part fp32 operands (see include/mlconfgen_hip.h)."""
-        if compute_dtype not in ("f32", "bf16", "f32x6", "f32x9"):
-            raise ValueError("compute_dtype must be 'f32', 'bf16', 'f32x6' or 'f32x9'")
-        _lib.check(_lib.lib().mcg_egnn_set_precision(self.handle, {"f32": 0, "bf16": 1, "f32x6": 2, "f32x9": 3}[compute_dtype]),
+        if compute_dtype not in ("f32", "bf16", "f32x6"):
+            raise ValueError("compute_dtype must be 'f32', 'bf16' or 'f32x6'")
+        _lib.check(_lib.lib().mcg_egnn_set_precision(self.handle, {"f32": 0, "bf16": 1, "f32x6": 2}[compute_dtype]),
                    "mcg_egnn_set_precision")
         if compute_dtype != self.compute_dtype:
             self._plans.clear()          # tilings differ between the precisions
         self.compute_dtype = compute_dtype
 
+    def set_option(self, option: int, value: int) -> None:
+        """Model-level measurement options (`mcg_egnn_set_option`: _lib.OPT_X6_GEMM / OPT_GEMM_RN / OPT_GEMM_X6_RN)."""
+        _lib.check(_lib.lib().mcg_egnn_set_option(self.handle, int(option), int(value)), "mcg_egnn_set_option")
+        self._plans.clear()          # captured graphs hold the old launch configuration
+
     # -- plans --------------------------------------------------------------------
-    def plan(self, n_nodes: torch.Tensor, max_n_nodes: int, edge_mt: int = 0) -> BatchPlan:
-        if edge_mt == 0 and self.compute_dtype in ("bf16", "f32x6", "f32x9") and int(n_nodes.min()) >= 6:
+    def plan(self, n_nodes: torch.Tensor, max_n_nodes: int, edge_mt: int = 0, four_tile_units: int = 0,
+             n_ranges: int = 0) -> BatchPlan:
+        """Cached plan for a batch of molecule sizes.  `edge_mt`, `four_tile_units`, `n_ranges`: `mcg_plan_opts`
+        (0 = the library's choice; tests and measurement tools pass them explicitly)."""
+        if edge_mt == 0 and self.compute_dtype in ("bf16", "f32x6") and int(n_nodes.min()) >= 6:
             edge_mt = 4          # 64-row workgroup tiles (needs <= 16 nodes per 64 edge rows)
-        # split-operand modes: two molecule ranges on two streams from ~1 500 edge tiles on (their edge kernel is short
+        # split-operand mode: two molecule ranges on two streams from ~1 500 edge tiles on (its edge kernel is short
         # against the node phase, which the other range's edge kernel then overlaps: 3.53 -> 3.18 ms at config 2)
-        n_ranges = 0
-        if edge_mt == 4 and self.compute_dtype in ("f32x6", "f32x9"):
+        if n_ranges == 0 and edge_mt == 4 and self.compute_dtype == "f32x6":
             nn = n_nodes.reshape(-1).to(torch.long)
             n_ranges = 2 if int((nn * (nn - 1)).sum()) >= 1500 * 16 else 1
-        key = (int(max_n_nodes), int(edge_mt), tuple(int(v) for v in n_nodes.reshape(-1).tolist()))
+        key = (int(max_n_nodes), int(edge_mt), int(four_tile_units), int(n_ranges), tuple(int(v) for v in n_nodes.reshape(-1).tolist()))
         p = self._plans.get(key)
         if p is None:
             if len(self._plans) >= 4:
                 self._plans.pop(next(iter(self._plans)))
-            p = BatchPlan(n_nodes, max_n_nodes, self.device, edge_mt, n_ranges)
+            p = BatchPlan(n_nodes, max_n_nodes, self.device, edge_mt, n_ranges, four_tile_units)
             self._plans[key] = p
         return p
 

@@ -96,7 +96,14 @@ class EquivariantDiffusion(torch.nn.Module):
         return rx, rh
 
     class _Run:
-        """State of one sampling call: plan, device context, time table, scratch."""
+        """State of one sampling call: plan, device context, time table, scratch.
+
+        The latent `z`, the network output and the context live in buffers OWNED BY THE CACHED PLAN (so that the captured
+        HIP graph is replayed, not re-captured).  A plan - and therefore a sampling run over a given batch of sizes - is
+        single-stream and non-reentrant, like the reference's sampler (one Python thread, one stream): two runs that
+        resolve to the same plan must not overlap in time (threads, streams, or two EquivariantDiffusion objects over one
+        dynamics).  What a run RETURNS (`x`, `h` of `_decode`, the tensor of `sample_combined_position_feature_noise`) is
+        always a fresh tensor and is never overwritten by a later run; the in-place latent handed to `trace` is cloned."""
 
         def __init__(self, model: "EquivariantDiffusion", node_mask, context):
             dev = model.device

@@ -226,34 +226,37 @@ def test_div100_three_fma_form_equals_ieee_division(tmp_path):
     assert " 0 of them" in r.stdout
 
 
-def _check_tables(sizes, N, cus, edge_mt=1):
+def _check_tables(sizes, N, cus, edge_mt=1, four_tile_units=0):
+    import ctypes as C
     from ml_conformer_generator_amd import _lib
     L = _lib.lib()
     a = np.asarray(sizes, dtype=np.int32)
     info = np.zeros(8, dtype=np.int32)
-    rc = L.mcg_plan_check_tables(len(a), int(N), a.ctypes.data, edge_mt, cus, info.ctypes.data)
+    opts = _lib.PlanOpts(edge_mt=edge_mt, four_tile_units=four_tile_units)
+    rc = L.mcg_plan_check_tables(len(a), int(N), a.ctypes.data, C.byref(opts), cus, info.ctypes.data)
     return rc, info.tolist(), (L.mcg_last_error().decode() if rc else "")
 
 
-@pytest.mark.parametrize("tail", [None, "0", "-1", "8", "24"])
-def test_plan_unit_tables_are_consistent_for_random_batches(tail, monkeypatch):
+def _random_batches(seed=99, trials=24):
+    g = torch.Generator().manual_seed(seed)
+    for trial in range(trials):
+        B = int(torch.randint(1, 40, (1,), generator=g))
+        lo, hi = [(2, 9), (6, 42), (15, 39), (1, 4), (27, 27), (40, 42)][trial % 6]
+        sizes = torch.randint(lo, hi + 1, (B,), generator=g).tolist()
+        yield trial, sizes, max(sizes), [1, 2, 4, 16, 256][trial % 5]
+
+
+@pytest.mark.parametrize("tail", [None, "all", -1, 8, 24])
+def test_plan_unit_tables_are_consistent_for_random_batches(tail):
     """The host half of mcg_plan_create (no GPU): for random batch compositions, device sizes (`cus`) and splits between
     four-tile and quarter-tile units, the library re-derives from the row table which (unit, tile, segment) every edge row
     falls into and checks it against the tables the kernels read: the row's slot is listed by its atom, no slot serves
     two atoms, every slot is written, a four-tile unit parks <= 16 rows, an atom lists at most as many slots as the
     table set declares (<= 4)."""
-    if tail is None:
-        monkeypatch.delenv("MCG_TAIL", raising=False)
-    else:
-        monkeypatch.setenv("MCG_TAIL", tail)
-    g = torch.Generator().manual_seed(99)
-    for trial in range(24):
-        B = int(torch.randint(1, 40, (1,), generator=g))
-        lo, hi = [(2, 9), (6, 42), (15, 39), (1, 4), (27, 27), (40, 42)][trial % 6]
-        sizes = torch.randint(lo, hi + 1, (B,), generator=g).tolist()
-        N = max(sizes)
-        cus = [1, 2, 4, 16, 256][trial % 5]
-        rc, info, err = _check_tables(sizes, N, cus)
+    from ml_conformer_generator_amd import _lib
+    four_tile = 0 if tail is None else _lib.ALL_FOUR_TILE if tail == "all" else tail
+    for trial, sizes, N, cus in _random_batches():
+        rc, info, err = _check_tables(sizes, N, cus, four_tile_units=four_tile)
         assert rc == 0, (trial, sizes, cus, err)
         n_sets, units0, full0, slots0, span0, units1, slots1, span1 = info
         rows = sum(n * (n - 1) for n in sizes)
@@ -268,8 +271,42 @@ def test_plan_unit_tables_are_consistent_for_random_batches(tail, monkeypatch):
         assert units0 == full0 + (tiles - 4 * full0 if full0 < wg_all else 0)
         if n_sets == 2:
             assert units1 == wg_all and span1 == 2 and slots1 <= slots0
-        if tail == "0" and n_sets == 1:      # four-tile units only - unless 64 rows would touch more than 16 (tiny) atoms
+        if tail == "all" and n_sets == 1:      # four-tile units only - unless 64 rows would touch more than 16 (tiny) atoms
             assert full0 == wg_all or (full0 == 0 and min(sizes) <= 6)
+
+
+def test_plan_builder_under_address_and_ub_sanitizers(tmp_path):
+    """SURVEY.md section 5 (host ASan on the shim): the HOST half of mcg_plan_create_ex - mcg_plan_host.cpp, plain C++ -
+    built with -fsanitize=address,undefined by `make asan` (CPU only; GPU sanitizers are not available on this pool) and
+    driven over the random batches of the test above x every four-tile / quarter-tile split, plus the refused cases.
+    Any out-of-range access in the table construction (the round-1 advisor found one) aborts the driver."""
+    import shutil
+    import subprocess
+    csrc = os.path.join(REPO, "ml_conformer_generator_amd", "csrc")
+    exe = os.path.join(REPO, "tools", "native", "plan_host_check")
+    if shutil.which("make") is None:
+        pytest.skip("no make")
+    r = subprocess.run(["make", "-C", csrc, "asan"], capture_output=True, text=True)
+    if r.returncode != 0:
+        if "sanitizer" in r.stderr or "asan" in r.stderr or "cannot find" in r.stderr or "No such file" in r.stderr:
+            pytest.skip("this toolchain has no AddressSanitizer runtime: " + r.stderr[-300:])
+        raise AssertionError(r.stderr[-2000:])
+    lines = []
+    for four_tile in (0, 0x3fffffff, -1, 8, 24):
+        for trial, sizes, N, cus in _random_batches(seed=1234, trials=30):
+            lines.append(" ".join(map(str, [N, cus, 1, four_tile, 1] + sizes)))
+    lines.append(" ".join(map(str, [27, 256, 1, 0, 1] + [27] * 64)))                  # configs[1]
+    lines.append(" ".join(map(str, [42, 256, 0, 0, 1] + [42] * 6)))
+    lines.append(" ".join(map(str, [39, 256, 4, 0, 1] + [15 + (7 * i) % 25 for i in range(256)])))     # 64-row units
+    lines.append(" ".join(map(str, [2, 256, 4, 0, 0] + [2] * 33)))                    # refused: > 16 atoms per 64-row unit
+    lines.append(" ".join(map(str, [5, 256, 1, 0, 0] + [6, 3])))                      # refused: n_nodes > N
+    lines.append(" ".join(map(str, [60, 256, 1, 0, 1] + [60, 55, 47])))               # no unit tables (N > ~50): row table only
+    f = tmp_path / "batches.txt"
+    f.write_text("\n".join(lines) + "\n")
+    r = subprocess.run([exe, str(f)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+    assert f"checked {len(lines)} batches" in r.stdout and " 0 unexpected outcomes" in r.stdout
 
 
 def test_plan_unit_tables_at_the_bench_shapes():
@@ -286,3 +323,26 @@ def test_plan_unit_tables_at_the_bench_shapes():
     # wide units cannot hold 33 two-atom molecules (64 row-owning atoms in one 64-row unit): refused, with a message
     rc, info, err = _check_tables([2] * 33, 2, 256, edge_mt=4)
     assert rc != 0 and "edge_mt" in err
+
+
+def test_finish_without_rdkit_filters_by_proxy_and_warns_once():
+    """Return-type contract where RDKit is absent (this container, the GPU boxes): GeneratedMolecule records that pass the
+    labelled proxy; `optimise_geometry=True` cannot be honoured and says so once per process."""
+    import warnings
+    from ml_conformer_generator_amd import conformer_generator as CG
+    from ml_conformer_generator_amd import rdkit_finish
+    from ml_conformer_generator_amd.handoff import GeneratedMolecule
+    if CG.HAVE_RDKIT:
+        pytest.skip("RDKit is installed: the reference's own gate runs instead")
+    assert not rdkit_finish.have_rdkit()
+    mols = [GeneratedMolecule([6, 8], torch.zeros(2, 3), torch.tensor([[0, 1], [1, 0]], dtype=torch.int8), valid=v)
+            for v in (True, False, True)]
+    CG._WARNED_NO_MMFF[0] = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        kept, frac = CG._finish(mols, True)
+        kept2, _ = CG._finish(mols, True)
+    assert len(kept) == 2 and abs(frac - 2 / 3) < 1e-9 and len(kept2) == 2
+    assert sum("optimise_geometry" in str(x.message) for x in w) == 1          # once per process
+    assert CG._finish([], True) == ([], 0.0)
+    assert "V2000" in mols[0].to_molblock() and "M  END" in mols[0].to_molblock()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmarks on the GPU box: edge kernel per launch, one full denoiser call (phi).
-Usage: python tools/bench_kernels.py [--shape c2|c3] [--mt 0|1|2]"""
+Usage: python tools/bench_kernels.py [--shape c2|c3] [--mt 0|1|4] [--four-tile-units n|-1|all] [--ranges n] [--latency-mode m]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,6 +14,9 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--dtype", default="f32")
 ap.add_argument("--mols", type=int, default=0, help="override: this many molecules of --atoms atoms")
 ap.add_argument("--atoms", type=int, default=27)
+ap.add_argument("--four-tile-units", default="0", help="mcg_plan_opts.four_tile_units: 0 auto, -1 none, n, or 'all'")
+ap.add_argument("--ranges", type=int, default=0, help="mcg_plan_opts.n_ranges (0 = the library's choice)")
+ap.add_argument("--latency-mode", type=int, default=-1, help="mcg_plan_set_latency_mode: -1 auto, 0 four-tile units only, 1 k_edge_ns")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 dyn = EGNNDynamics(device=dev)
@@ -25,7 +28,10 @@ elif a.shape == "c2":
     sizes = torch.full((64,), 27, dtype=torch.int32); N = 27
 else:
     torch.manual_seed(7); sizes = torch.randint(15, 40, (256,)).to(torch.int32); N = 39
-plan = dyn.plan(sizes, N, edge_mt=a.mt)
+ftu = _lib.ALL_FOUR_TILE if a.four_tile_units == "all" else int(a.four_tile_units)
+plan = dyn.plan(sizes, N, edge_mt=a.mt, four_tile_units=ftu, n_ranges=a.ranges)
+if a.latency_mode >= 0:
+    plan.set_latency_mode(a.latency_mode)
 B = sizes.numel()
 z = torch.randn(B, N, 11, device=dev); ctx = torch.zeros(B, N, 3, device=dev); t = torch.full((B,), 0.5, device=dev)
 out = dyn.run(plan, t, z, ctx)

@@ -3,6 +3,6 @@
 R=$GRAFT_REPO_ROOT
 for mols in $1; do
 for sp in $2; do
-  echo -n "[mols=$mols MCG_SPLIT=$sp] "; MCG_SPLIT=$sp python3 $R/tools/bench_kernels.py --mols $mols --iters 10 | sed 's/dtype=f32 shape=c2 mt=1//'
+  echo -n "[mols=$mols n_ranges=$sp] "; python3 $R/tools/bench_kernels.py --mols $mols --iters 10 --ranges $sp | sed 's/dtype=f32 shape=c2 mt=1//'
 done
 done
