@@ -378,13 +378,23 @@ def time_edge_kernel_in_call(gen, plan, dev, calls=3):
     for n_calls in (1, calls):            # one untimed-for-the-result warm call, then the measured ones
         _lib.check(L.mcg_bench_edge_incall(dyn.handle, plan.handle, _lib.dptr(t), _lib.dptr(xh), _lib.dptr(ctx), _lib.dptr(out),
                                            n_calls, us.ctypes.data, stream), "mcg_bench_edge_incall")
-    return float(us[0]) * 1e-6, float(us[1]) * 1e-6, int(us[2])
+    n_ranges = int(round(float(us[2]) / (2 * dyn.n_blocks * calls))) if us[2] else 0
+    return float(us[0]) * 1e-6, float(us[1]) * 1e-6, int(us[2]), n_ranges
 
 
 def edge_roofline(args, gen, dev, dtype, traffic=None, traffic_source=None):
     plan = next(reversed(gen.generative_model.dynamics._plans.values()))
     sa_mean, sa_best = time_edge_kernel(gen, plan, dev)
-    edge_s, equiv_s, n_timed = time_edge_kernel_in_call(gen, plan, dev)
+    edge_s, equiv_s, n_timed, n_ranges = time_edge_kernel_in_call(gen, plan, dev)
+    timing = ("mean of the GCL edge launches of 3 whole denoiser calls issued as plain launches, each launch's own begin / end "
+              "timestamps (hipExtLaunchKernelGGL events on the launching stream)")
+    if n_ranges != 1:
+        # the plan cuts the batch into molecule ranges whose edge kernels OVERLAP on separate streams: a per-launch time of
+        # one range is not the time of the batch's edge layer.  The roofline figure is then the kernel over the WHOLE batch
+        # launched alone (mcg_bench_edge on the parent plan's own tables).
+        edge_s, equiv_s = sa_mean, None
+        timing = (f"the plan runs {n_ranges} molecule ranges on separate streams (overlapping edge kernels); timed instead: the "
+                  "kernel over the whole batch alone, HIP events around 3 batches of 20 back-to-back launches, mean")
     fl = edge_flops_per_launch(plan.n_real_edges)
     if dtype == "f32x6":
         fl *= 6.0          # executed bf16 FLOPs: six partial products per fp32 product (K padded 420 -> 448 not counted)
@@ -394,9 +404,8 @@ def edge_roofline(args, gen, dev, dtype, traffic=None, traffic_source=None):
                   "bound": "mfma", "achieved": achieved, "peak": peak_tf, "unit": "TFLOP/s",
                   "frac": achieved / peak_tf, "traffic": traffic, "traffic_source": traffic_source,
                   "avg_launch_us": edge_s * 1e6, "launches_timed": n_timed,
-                  "launch_timing": "mean of the GCL edge launches of 3 whole denoiser calls, each launch's own begin / end "
-                                   "timestamps (hipExtLaunchKernelGGL events on the launching stream)",
-                  "coordinate_variant_avg_launch_us": equiv_s * 1e6,
+                  "launch_timing": timing, "molecule_ranges": n_ranges,
+                  "coordinate_variant_avg_launch_us": equiv_s * 1e6 if equiv_s else None,
                   "standalone_avg_launch_us": sa_mean * 1e6, "standalone_best_launch_us": sa_best * 1e6,
                   "standalone_timing": "HIP events around 3 batches of 20 back-to-back launches of this kernel alone: mean / best batch",
                   "flops_per_launch": fl}
@@ -662,7 +671,15 @@ def main():
         if default_line and not args.no_config2:
             # BASELINE configs[2] (256 ragged molecules, 15..39 atoms) timed in the same run: 1 warm-up + 2 passes
             el2, ms2, fin2, vf2 = timed_passes(gen, ctx, 256, 27, 12, {}, 2, 1, fence)
-            _, roof2 = edge_roofline(args, gen, dev, args.dtype)
+            tr2 = ts2 = None
+            try:
+                e2 = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))["configs[2] shape: n_samples=256, n=27+-12"]
+                tr2 = e2["traffic_bytes_corrected_per_layer"]
+                ts2 = ("profiles/pmc_traffic.json (static: separate rocprofv3 --pmc passes, " + e2["round"] + "; three range-launches "
+                       "per layer summed, FETCH_SIZE x2 gfx950 correction)")
+            except Exception:  # noqa: BLE001
+                pass
+            _, roof2 = edge_roofline(args, gen, dev, args.dtype, tr2, ts2)
             out["config2_ragged256"] = {
                 "workload": "configs[2] shape: n_samples=256, 27+-12 heavy atoms (ragged), diffusion_steps=100, " + mode_text,
                 "value": 256 * 2 / el2, "unit": "molecules/s", "steps": 2, "warmup": 1, "ms_per_step": el2 / 2 * 1e3,

@@ -98,30 +98,41 @@ __global__ __launch_bounds__(128) void k_gather_agg2(const float* __restrict__ U
 // mean removed; padded slots of out[B,N,11] are zero  (egnn.py:398-399, :499-513).
 // `ux` / `slots2` (optional): the last block's coordinate update, still pending as workgroup-level sums
 // (x_final = x + (ux[s.x] + .. + ux[s.w]) / 100, egnn.py:128-148).
-__global__ __launch_bounds__(512) void k_output(const float* __restrict__ h, const float* __restrict__ x,
+// One WAVE per real atom (M waves; round 2 ran one workgroup per MOLECULE - 64 workgroups at configs[1], 16.8 us per
+// launch), followed by one wave per molecule that zeroes its padded slots.  Every atom's wave recomputes the molecule's
+// velocity mean (n <= N loads of 16 bytes, same order as before: lane-strided partial sums, xor butterfly).
+__global__ __launch_bounds__(256) void k_output(const float* __restrict__ h, const float* __restrict__ x,
                                                  const float* __restrict__ x0, const int* __restrict__ n_nodes,
-                                                 const int* __restrict__ node_off, int N,
-                                                 const float* __restrict__ out_w,  // [12][HP]
+                                                 const int* __restrict__ node_off, const int* __restrict__ node_mol, int M, int B,
+                                                 int N, const float* __restrict__ out_w,  // [12][HP]
                                                  const float* __restrict__ out_b, float* __restrict__ out,
                                                  const float* __restrict__ ux, const int4* __restrict__ slots2) {
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= M) {                                   // padded slots of molecule w - M
+        const int b = w - M;
+        if (b >= B) return;
+        const int n = n_nodes[b];
+        float* ob = out + ((size_t)b * N + n) * 11;
+        for (int k = lane; k < (N - n) * 11; k += 64) ob[k] = 0.f;
+        return;
+    }
+    const int b = node_mol[w];
     const int n = n_nodes[b];
     const int v0 = node_off[b];
-    // velocity of atom i, component k (with the pending coordinate update folded in)
+    // velocity of atom i (with the pending coordinate update folded in)
     auto vel = [&](int i) {
         const size_t v = (size_t)(v0 + i);
         f32x4 xv = *reinterpret_cast<const f32x4*>(x + v * 4);
         if (ux) {
             const int4 sl = slots2[v];
-            const f32x4 a = *reinterpret_cast<const f32x4*>(ux + (size_t)sl.x * 4), b = *reinterpret_cast<const f32x4*>(ux + (size_t)sl.y * 4);
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ux + (size_t)sl.x * 4), c = *reinterpret_cast<const f32x4*>(ux + (size_t)sl.y * 4);
             const f32x4 d = *reinterpret_cast<const f32x4*>(ux + (size_t)sl.z * 4), e = *reinterpret_cast<const f32x4*>(ux + (size_t)sl.w * 4);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) xv[k] += (((a[k] + b[k]) + d[k]) + e[k]) / NORM;
+            for (int k = 0; k < 3; ++k) xv[k] += (((a[k] + c[k]) + d[k]) + e[k]) / NORM;
         }
         return xv - *reinterpret_cast<const f32x4*>(x0 + v * 4);
     };
-    // masked mean of the velocity (every wave computes it: n <= N lanes' worth of work)
     float sx = 0.f, sy = 0.f, sz = 0.f;
     for (int i = lane; i < n; i += 64) { const f32x4 d = vel(i); sx += d[0]; sy += d[1]; sz += d[2]; }
     for (int o = 32; o > 0; o >>= 1) {
@@ -129,36 +140,30 @@ __global__ __launch_bounds__(512) void k_output(const float* __restrict__ h, con
     }
     const float inv_n = n > 0 ? 1.0f / (float)n : 0.f;
     const float mx = sx * inv_n, my = sy * inv_n, mz = sz * inv_n;
-    float* ob = out + (size_t)b * N * 11;
-    for (int i = wid; i < N; i += 8) {          // one wave per node slot
-        float* o = ob + (size_t)i * 11;
-        if (i >= n) {
-            if (lane < 11) o[lane] = 0.f;
-            continue;
-        }
-        const float* hr = h + (size_t)(v0 + i) * HP;
-        float accv[8];
+    const int i = w - v0;
+    const float* hr = h + (size_t)w * HP;
+    float accv[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) accv[k] = 0.f;
-        for (int col = lane; col < H; col += 64) {
-            const float hv = hr[col];
+    for (int k = 0; k < 8; ++k) accv[k] = 0.f;
+    for (int col = lane; col < H; col += 64) {
+        const float hv = hr[col];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) accv[k] = fmaf(hv, out_w[k * HP + col], accv[k]);
-        }
+        for (int k = 0; k < 8; ++k) accv[k] = fmaf(hv, out_w[k * HP + col], accv[k]);
+    }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float s = accv[k];
-            for (int of = 32; of > 0; of >>= 1) s += __shfl_xor(s, of, 64);
-            accv[k] = s + out_b[k];
-        }
-        if (lane == 0) {
-            const f32x4 d = vel(i);
-            o[0] = d[0] - mx;
-            o[1] = d[1] - my;
-            o[2] = d[2] - mz;
+    for (int k = 0; k < 8; ++k) {
+        float s = accv[k];
+        for (int of = 32; of > 0; of >>= 1) s += __shfl_xor(s, of, 64);
+        accv[k] = s + out_b[k];
+    }
+    if (lane == 0) {
+        float* o = out + ((size_t)b * N + i) * 11;
+        const f32x4 d = vel(i);
+        o[0] = d[0] - mx;
+        o[1] = d[1] - my;
+        o[2] = d[2] - mz;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) o[3 + k] = accv[k];
-        }
+        for (int k = 0; k < 8; ++k) o[3 + k] = accv[k];
     }
 }
 
@@ -340,8 +345,8 @@ static int dynamics_launch(const mcg_egnn* m, mcg_plan* pl, const float* t, cons
             if (int e = run_block(m, pl, b, s)) return e;
     }
     // (the last block's coordinate update is folded into the output head)
-    hipLaunchKernelGGL(k_output, dim3(pl->B), dim3(512), 0, s, pl->h, pl->x, pl->x0, pl->n_nodes, pl->node_off, pl->N,
-                       m->out_w, m->out_b, out, pl->x_pending ? pl->Ux : (const float*)nullptr,
+    hipLaunchKernelGGL(k_output, dim3((pl->M + pl->B + 3) / 4), dim3(256), 0, s, pl->h, pl->x, pl->x0, pl->n_nodes, pl->node_off,
+                       pl->node_mol, pl->M, pl->B, pl->N, m->out_w, m->out_b, out, pl->x_pending ? pl->Ux : (const float*)nullptr,
                        pl->x_pending ? pl->units().node_slots : (const int4*)nullptr);
     MCG_HIP(hipGetLastError());
     pl->x_pending = false;
