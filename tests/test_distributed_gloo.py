@@ -205,3 +205,33 @@ def test_bench_refuses_to_report_fewer_gpus_than_asked():
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0
     assert '"n_gpus"' not in r.stdout
+
+
+def test_bench_counts_gpus_without_touching_hip_and_ends_all_ranks_when_one_fails():
+    """`bench.py --gpus N` parent: devices are counted from the KFD topology in sysfs (no HIP call), and a rank that dies
+    takes the others down with it - here (no GPU in this container) every child dies at `torch.cuda.set_device`; with the
+    gloo dry-run switch the parent does spawn them, must notice, end the rest, print no JSON line and exit non-zero well
+    inside the collective timeout."""
+    import importlib.util
+    import subprocess
+    import sys
+    import time
+    from conftest import REPO
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = bench.count_gpus_without_hip()
+    assert n is None or (isinstance(n, int) and n >= 0)
+    assert not torch.cuda.is_initialized()
+    if torch.cuda.device_count() >= 1:
+        return                      # a GPU box: the dry run itself is exercised by profiles/round*_bench_2rank_gloo*.json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MCG_DIST_BACKEND"] = "gloo"
+    env["MCG_BENCH_TIMEOUT"] = "240"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=400)
+    assert r.returncode != 0
+    assert '"n_gpus"' not in r.stdout
+    assert "child ranks exited" in r.stderr
+    assert time.time() - t0 < 300
