@@ -356,7 +356,7 @@ def x6_probe(args, gen, sd, gsd, ctx, dev):
                     "accumulates in fp32; passes the same fp32 parity tolerance as the exact kernel (DESIGN.md)"}
 
 
-def time_edge_kernel_in_call(gen, plan, dev, calls=3):
+def time_edge_kernel_in_call(gen, plan, dev, calls=8):
     """Mean duration of the GCL edge kernel INSIDE whole denoiser calls: the kernel's own begin / end timestamps
     (hipExtLaunchKernelGGL events on the launching stream, `mcg_bench_edge_incall`), 18 launches per call behind and in
     front of the node GEMMs - the context the sampler runs it in, and the figure a rocprofv3 kernel trace of the timed
@@ -375,7 +375,7 @@ def time_edge_kernel_in_call(gen, plan, dev, calls=3):
     out = torch.empty_like(xh)
     us = np.zeros(4, dtype=np.float32)
     stream = _lib.current_stream_ptr(dev)
-    for n_calls in (1, calls):            # one untimed-for-the-result warm call, then the measured ones
+    for n_calls in (2, calls):            # two warm calls (clocks, caches), then the measured ones
         _lib.check(L.mcg_bench_edge_incall(dyn.handle, plan.handle, _lib.dptr(t), _lib.dptr(xh), _lib.dptr(ctx), _lib.dptr(out),
                                            n_calls, us.ctypes.data, stream), "mcg_bench_edge_incall")
     n_ranges = int(round(float(us[2]) / (2 * dyn.n_blocks * calls))) if us[2] else 0
@@ -386,7 +386,7 @@ def edge_roofline(args, gen, dev, dtype, traffic=None, traffic_source=None):
     plan = next(reversed(gen.generative_model.dynamics._plans.values()))
     sa_mean, sa_best = time_edge_kernel(gen, plan, dev)
     edge_s, equiv_s, n_timed, n_ranges = time_edge_kernel_in_call(gen, plan, dev)
-    timing = ("mean of the GCL edge launches of 3 whole denoiser calls issued as plain launches, each launch's own begin / end "
+    timing = ("mean of the GCL edge launches of 8 whole denoiser calls issued as plain launches, each launch's own begin / end "
               "timestamps (hipExtLaunchKernelGGL events on the launching stream)")
     if n_ranges != 1:
         # the plan cuts the batch into molecule ranges whose edge kernels OVERLAP on separate streams: a per-launch time of

@@ -187,10 +187,9 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
     a.wg_info = T.wg_info; a.U = equiv ? pl->Ux : pl->U;
     a.n_full_wg = T.n_full_wg; a.Bp4 = L.w2_Bp4;
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (pl->edge_timing) {              // mcg_bench_edge_incall: the kernel's own begin / end timestamps
-        MCG_HIP(hipEventCreate(&t0));
-        MCG_HIP(hipEventCreate(&t1));
-        pl->edge_timing->push_back({t0, t1, equiv});
+    if (pl->edge_timing && *pl->edge_timing_next < pl->edge_timing->size()) {     // mcg_bench_edge_incall
+        mcg_plan::EdgeTiming& e = (*pl->edge_timing)[(*pl->edge_timing_next)++];
+        t0 = e.t0; t1 = e.t1; e.equiv = equiv; e.used = true;
     }
     if (wgc) {
         MCG_HIP(mcg_launch_edge_exact(a, equiv, T.n_units, s, t0, t1));
@@ -450,20 +449,34 @@ int mcg_bench_edge_incall(const mcg_egnn* m, mcg_plan* pl, const float* t, const
                           int calls, float* us_host /*[4]*/, void* stream) {
     if (!m || !pl || !t || !xh || !context || !out || !us_host || calls < 1) return MCG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    std::vector<mcg_plan::EdgeTiming> ev;
-    pl->edge_timing = &ev;
-    for (mcg_plan* q : pl->subs) q->edge_timing = &ev;         // (host-side bookkeeping: launches are issued by this thread)
+    // event pairs are created up front: nothing but launches between the kernels of a call (the GPU must not idle between
+    // them - it clocks down within microseconds and the next kernel would be timed on the ramp)
+    const size_t n_ranges = pl->subs.empty() ? 1 : pl->subs.size();
+    std::vector<mcg_plan::EdgeTiming> ev((size_t)calls * 3 * m->n_blocks * n_ranges);
+    for (auto& e : ev) {
+        e.equiv = e.used = false;
+        e.t0 = e.t1 = nullptr;
+        if (hipEventCreate(&e.t0) != hipSuccess || hipEventCreate(&e.t1) != hipSuccess) {
+            for (auto& q : ev) { if (q.t0) (void)hipEventDestroy(q.t0); if (q.t1) (void)hipEventDestroy(q.t1); }
+            mcg_set_error("mcg_bench_edge_incall: hipEventCreate failed");
+            (void)hipGetLastError();
+            return MCG_ERR_HIP;
+        }
+    }
+    size_t cursor = 0;
+    pl->edge_timing = &ev; pl->edge_timing_next = &cursor;
+    for (mcg_plan* q : pl->subs) { q->edge_timing = &ev; q->edge_timing_next = &cursor; }   // (launches are issued by this thread)
     int rc = MCG_OK;
     for (int i = 0; i < calls && rc == MCG_OK; ++i) rc = dynamics_launch(m, pl, t, xh, context, out, s);
-    pl->edge_timing = nullptr;
-    for (mcg_plan* q : pl->subs) q->edge_timing = nullptr;
+    pl->edge_timing = nullptr; pl->edge_timing_next = nullptr;
+    for (mcg_plan* q : pl->subs) { q->edge_timing = nullptr; q->edge_timing_next = nullptr; }
     const hipError_t se = hipStreamSynchronize(s);
     for (hipStream_t st : pl->streams) (void)hipStreamSynchronize(st);
     double sum[2] = {0.0, 0.0};
     int cnt[2] = {0, 0};
     for (const auto& e : ev) {
         float ms = 0.f;
-        if (rc == MCG_OK && se == hipSuccess && hipEventElapsedTime(&ms, e.t0, e.t1) == hipSuccess) { sum[e.equiv] += ms * 1e3; ++cnt[e.equiv]; }
+        if (e.used && rc == MCG_OK && se == hipSuccess && hipEventElapsedTime(&ms, e.t0, e.t1) == hipSuccess) { sum[e.equiv] += ms * 1e3; ++cnt[e.equiv]; }
         (void)hipEventDestroy(e.t0);
         (void)hipEventDestroy(e.t1);
     }

@@ -141,8 +141,9 @@ struct mcg_plan {
     int latency_mode = -1;                  // -1 auto; 0: four-tile units only; 1: the stand-alone column-split kernel (k_edge_ns)
     // mcg_bench_edge_incall: when set, every edge launch of a (plain, un-captured) denoiser call is bracketed by a pair
     // of events that receive the kernel's own begin / end timestamps
-    struct EdgeTiming { hipEvent_t t0, t1; bool equiv; };
-    std::vector<EdgeTiming>* edge_timing = nullptr;
+    struct EdgeTiming { hipEvent_t t0, t1; bool equiv, used; };
+    std::vector<EdgeTiming>* edge_timing = nullptr;       // pool of pre-created event pairs (no API call between launches)
+    size_t* edge_timing_next = nullptr;                   // shared cursor into the pool
 };
 
 // small device-memory helpers shared by the model and plan builders
