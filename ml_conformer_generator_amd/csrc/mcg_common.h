@@ -81,6 +81,14 @@ __device__ __forceinline__ f32x4 mcg_mfma(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 blocks (lanes 4b .. 4b+3 = block b), D[b][i][j] += A[b][i] * B[b][j];
+// lane 4b + i holds A, lane 4b + j holds B and the four results D[b][0..3][j].  8 issue cycles against the 32 of
+// mcg_mfma at the same FLOP rate per cycle (tools/native/mfma4x4_probe.hip): used for the 4 real columns of the 27th
+// column tile of the edge MLP's second layer (420 = 26 x 16 + 4).
+__device__ __forceinline__ f32x4 mcg_mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ f32x4 mcg_mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }

@@ -365,6 +365,23 @@ __device__ __forceinline__ void edge_quarter_body(const EdgeArgs& p, int unit, i
 // load latency no longer sits in front of the matrix pipe.
 constexpr int PD = 6;                              // depth of the B-fragment register ring
 
+// 27th column tile: from the 4x4-block layout of mcg_mfma4 (lane (c, g), register i: k-slice g, row 4 ((c >> 2) & 3) + i,
+// column 416 + (c & 3)) to the 16x16 C/D layout of the other tiles (lane (c, g), register r: row 4 g + r, column 16 nt + c;
+// the 12 padded columns are zero).  The four k-slices are added in the fixed order (g ^ 0 + g ^ 1) + (g ^ 2 + g ^ 3).
+__device__ __forceinline__ f32x4 tile27_finish(f32x4 m, int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    f32x4 out;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v = m[r];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        const float w = __shfl(v, 20 * g + c, 64);          // the lane whose row block is g and whose column is c
+        out[r] = c < 4 ? w : 0.f;
+    }
+    return out;
+}
+
 template <bool EQUIV>
 __global__ __launch_bounds__(256, 2) void k_edge_lds(EdgeArgs p) {
     constexpr int MT = 1;          // 16 rows per wave (32 measured slower at configs 2 and 3: one workgroup per CU)
@@ -408,6 +425,16 @@ __global__ __launch_bounds__(256, 2) void k_edge_lds(EdgeArgs p) {
             const float b0 = p.b2[nt * 16 + c];
             acc[mt][nt] = (f32x4){b0, b0, b0, b0};
         }
+    // The 27th column tile holds 4 real columns (420 = 26 x 16 + 4).  It is accumulated with v_mfma_f32_4x4x1_16b_f32 -
+    // 8 issue cycles per k-step instead of 32: lane (c, g) then carries, in register i, the partial sum over the k-slice
+    // of lane group g (k = 16 q + 4 g + s, exactly the lane's A operand) for row 4 ((c >> 2) & 3) + i and column
+    // 416 + (c & 3); the four k-slices are added and moved to the 16x16 C/D layout after the loop (tile27_finish).
+    // Only the k-slice of lane group 0 starts from the bias.
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const float b0 = g == 0 ? p.b2[(NT - 1) * 16 + (c & 3)] : 0.f;
+        acc[mt][NT - 1] = (f32x4){b0, b0, b0, b0};
+    }
 
     // operand addresses: buffer descriptor + 32-bit lane offset + scalar group offset (no 64-bit VALU adds per load)
     const __amdgpu_buffer_rsrc_t rs_pab = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pab), 0, 0xffffffff, 0x00020000);
@@ -495,22 +522,27 @@ __global__ __launch_bounds__(256, 2) void k_edge_lds(EdgeArgs p) {
         }
         stage(q + 1, buf ^ 1);                                     // group q+1 (the tail group when q+1 == NG)
         const float* lb = lds + buf * GROUP_LDS_FLOATS + lane;
+        // tile 26 as 4x4 blocks: lane (c, g) needs W2[416 + (c & 3)][k of lane group g] = element 16 g + (c & 3) of the
+        // tile's 64-float line (4 lanes share an address: broadcast, 16 distinct banks)
+        const float* lbm = lds + buf * GROUP_LDS_FLOATS + 16 * g + (c & 3);
+        auto bfrag = [&](int idx) { return (idx % NT == NT - 1) ? lbm[idx * 64] : lb[idx * 64]; };
         f32x4 a4n[MT];
         // B fragments go through a PD-deep register ring: the ds_read of fragment i+PD is issued
         // right behind the MFMA(s) of fragment i, so LDS latency hides under PD*MT MFMAs of the SAME
         // wave (left alone hipcc emits "ds_read; s_waitcnt lgkmcnt(0); 2 MFMAs" back to back).
         float bq[PD];
 #pragma unroll
-        for (int i = 0; i < PD; ++i) bq[i] = lb[i * 64];
+        for (int i = 0; i < PD; ++i) bq[i] = bfrag(i);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int idx = s * NT + nt;
                 const float b = bq[idx % PD];
-                if (idx + PD < 4 * NT) bq[idx % PD] = lb[(idx + PD) * 64];
+                if (idx + PD < 4 * NT) bq[idx % PD] = bfrag(idx + PD);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mcg_mfma(a4[mt][s], b, acc[mt][nt]);
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][nt] = nt == NT - 1 ? mcg_mfma4(a4[mt][s], b, acc[mt][nt]) : mcg_mfma(a4[mt][s], b, acc[mt][nt]);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
                 __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);     // MT MFMAs
             }
@@ -533,11 +565,14 @@ __global__ __launch_bounds__(256, 2) void k_edge_lds(EdgeArgs p) {
         asm volatile("s_barrier" ::: "memory");
         const float* lb = lds + (NG & 1) * GROUP_LDS_FLOATS + lane;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+        for (int nt = 0; nt < NT - 1; ++nt) {
             const float b = lb[nt * 64];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mcg_mfma(a4[mt][0], b, acc[mt][nt]);
         }
+        const float bm = lds[(NG & 1) * GROUP_LDS_FLOATS + (NT - 1) * 64 + 16 * g + (c & 3)];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][NT - 1] = tile27_finish(mcg_mfma4(a4[mt][0], bm, acc[mt][NT - 1]), lane);
     }
     static_assert(MT == 1 && ((H / 16) & 1) == 0, "the tail k-step reads staging buffer 0: buffer 1 is the scratch");
     edge_epilogue_wg<EQUIV>(p, W, lane, wid, acc, R, lds + 2 * GROUP_LDS_FLOATS + HP, lds + GROUP_LDS_FLOATS);
