@@ -162,7 +162,8 @@ __device__ __forceinline__ void edge_epilogue_wg(const EdgeArgs& p, const WgSums
 //   * the layer-1 finish (A operand: 16 rows x 16 k per group) is generated ONCE per workgroup, waves 0..2 one group
 //     each per super-group of three, and published through a double-buffered LDS ring: one barrier per 48 k;
 //   * the gate / coordinate-head dot product needs one cross-wave exchange.
-// Accumulation order over k (bias first, then k ascending) is that of the four-tile body: m_ij is bit-identical.
+// Accumulation order over k (bias first, then k ascending) is that of the four-tile body: m_ij is bit-identical, except
+// the 4 real columns of the 27th tile, which the four-tile body accumulates as four k-slices (tile27_finish).
 constexpr int QT = 7;                               // column tiles per wave: nt = 7 * wid + i (wave 3: tile 26 twice)
 constexpr int Q_ABUF = 2 * 3 * 256;                 // floats: [2][3 groups][64 lanes] x 16 B
 constexpr int Q_TAILB = 26 * NT * 256;              // float offset of the tail k-step inside a B-pack4 (mcg_pack_b4)

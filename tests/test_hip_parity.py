@@ -125,7 +125,8 @@ def test_gcl_internals_vs_oracle(dyn, edm_sd):
     assert float(agg_ref.abs().max()) > 0.05 and float(msg_ref.abs().max()) > 0.1      # the pins carry signal
     # ORDER of the /100 (egnn.py:435): the reference and k_edge_ns's combine divide the finished sum, the workgroup-level
     # paths divide every partial row (one per unit an atom's rows run through) before the consumer adds them -
-    # a/100 + b/100 vs (a + b)/100.  m_ij is bit-identical between the edge paths; agg differs by that rounding only:
+    # a/100 + b/100 vs (a + b)/100.  m_ij is bit-identical between the edge paths (columns 416..419 of the four-tile body
+    # excepted: four k-slices on v_mfma_f32_4x4x1); agg differs by those roundings only:
     sc_agg = float(agg_ref.abs().max())
     for a in (-1, 0):
         d = float((aggs[a] - aggs[1]).abs().max())
