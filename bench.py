@@ -378,8 +378,7 @@ def time_edge_kernel_in_call(gen, plan, dev, calls=8):
     for n_calls in (2, calls):            # two warm calls (clocks, caches), then the measured ones
         _lib.check(L.mcg_bench_edge_incall(dyn.handle, plan.handle, _lib.dptr(t), _lib.dptr(xh), _lib.dptr(ctx), _lib.dptr(out),
                                            n_calls, us.ctypes.data, stream), "mcg_bench_edge_incall")
-    n_ranges = int(round(float(us[2]) / (2 * dyn.n_blocks * calls))) if us[2] else 0
-    return float(us[0]) * 1e-6, float(us[1]) * 1e-6, int(us[2]), n_ranges
+    return float(us[0]) * 1e-6, float(us[1]) * 1e-6, int(us[2]), plan.n_ranges
 
 
 def edge_roofline(args, gen, dev, dtype, traffic=None, traffic_source=None):

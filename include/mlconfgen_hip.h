@@ -95,6 +95,8 @@ int mcg_plan_set_latency_mode(mcg_plan* p, int mode);
 int mcg_plan_check_tables(int B, int N, const int32_t* n_nodes_host, const mcg_plan_opts* opts, int cus, int32_t* info_host);
 /* info[8] = {real nodes, real edges, edge_mt, edge waves, partial slots, B, N, 16-row edge tiles} */
 int mcg_plan_info(const mcg_plan* p, int32_t* info_host);
+/* number of molecule ranges (HIP streams) the plan actually runs: 1 = unsplit (small batches are never split) */
+int mcg_plan_ranges(const mcg_plan* p);
 
 /* ---- Op seam 1: out[B,N,11] = EGNNDynamics.forward(t[B,1], xh[B,N,11], node_mask, edge_mask,
  * context[B,N,3])  (egnn.py:472-513; called from equivariant_diffusion.py:187).  Masks are those of

@@ -179,6 +179,8 @@ int mcg_plan_set_latency_mode(mcg_plan* p, int mode) {
     return MCG_OK;
 }
 
+int mcg_plan_ranges(const mcg_plan* p) { return p ? (p->subs.empty() ? 1 : (int)p->subs.size()) : 0; }
+
 int mcg_plan_info(const mcg_plan* p, int32_t* info /*[8]*/) {
     if (!p || !info) return MCG_ERR_ARG;
     info[0] = p->M; info[1] = p->n_rows; info[2] = p->MT; info[3] = p->n_waves; info[4] = p->n_pslots;

@@ -39,6 +39,7 @@ class BatchPlan:
         _lib.check(L.mcg_plan_info(self._h, info.data_ptr()), "mcg_plan_info")
         (self.n_real_nodes, self.n_real_edges, self.edge_mt, self.n_edge_waves, self.n_pslots, _, _,
          self.n_edge_tiles) = [int(v) for v in info]
+        self.n_ranges = int(L.mcg_plan_ranges(self._h))      # molecule ranges (HIP streams) the plan really runs
 
     @property
     def handle(self):

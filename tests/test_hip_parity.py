@@ -235,22 +235,24 @@ def test_largest_molecules_span_four_quarter_tile_units(dyn, edm_sd):
 @pytest.mark.parametrize("n_ranges", [1, 2, 3])
 def test_dynamics_molecule_ranges_agree_with_oracle(dyn, edm_sd, n_ranges):
     """The same ragged batch as one plan and cut into 2 / 3 molecule ranges on separate HIP streams
-    (`mcg_plan_opts.n_ranges`; batches this small are not split by the library itself) against the oracle."""
+    (`mcg_plan_opts.n_ranges`; the library itself splits from 3 600 edge tiles on) against the oracle."""
     from oracle import egnn_oracle as EO
     from oracle import host_oracle as HO
     torch.manual_seed(5)
-    sizes = torch.tensor([15, 39, 22, 16, 31, 27])
-    N = 39
+    sizes = torch.tensor([15, 39, 22, 16, 31, 27] * 2)
+    B, N = sizes.numel(), 39
     nm, em = HO.masks_from_sizes(sizes, N)
-    z = torch.randn(6, N, 11) * nm * 3.0
-    ctx = torch.randn(1, 1, 3).repeat(6, N, 1) * nm
-    t = torch.full((6, 1), 0.37)
+    z = torch.randn(B, N, 11) * nm * 3.0
+    ctx = torch.randn(1, 1, 3).repeat(B, N, 1) * nm
+    t = torch.full((B, 1), 0.37)
     ref = EO.egnn_dynamics(edm_sd, t, z, nm, em, ctx)
     plan = dyn.plan(sizes, N, edge_mt=1, n_ranges=n_ranges)
-    assert plan.edge_mt == 1
+    assert plan.edge_mt == 1 and plan.n_ranges == n_ranges
     out = dyn.run(plan, t.reshape(-1).to(DEV), z.to(DEV), ctx.to(DEV))
     ok, err, sc = close(out, ref)
     assert ok, f"err {err} scale {sc}"
+    out2 = dyn.run(plan, t.reshape(-1).to(DEV), z.to(DEV), ctx.to(DEV))
+    assert torch.equal(out, out2)
 
 
 def test_dynamics_full_gain_weights_vs_oracle():
