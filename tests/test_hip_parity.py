@@ -255,6 +255,54 @@ def test_dynamics_molecule_ranges_agree_with_oracle(dyn, edm_sd, n_ranges):
     assert torch.equal(out, out2)
 
 
+def test_model_options_and_measurement_hooks(edm_sd):
+    """`mcg_egnn_set_option` (node-GEMM tile widths, split-operand GEMMs on / off) changes launch shapes, never results
+    beyond fp32 re-association: every setting against the oracle under the stated tolerance.  `mcg_bench_edge_incall`
+    times 18 + 9 edge launches per call and range and leaves the plan usable."""
+    import numpy as np
+    from ml_conformer_generator_amd import _lib
+    from ml_conformer_generator_amd.egnn import EGNNDynamics
+    from oracle import egnn_oracle as EO
+    from oracle import host_oracle as HO
+    torch.manual_seed(17)
+    sizes = torch.tensor([21, 27, 15, 33, 18])
+    B, N = sizes.numel(), 33
+    nm, em = HO.masks_from_sizes(sizes, N)
+    z = torch.randn(B, N, 11) * nm
+    ctx = torch.randn(B, 1, 3).repeat(1, N, 1) * nm
+    t = torch.full((B, 1), 0.45)
+    ref = EO.egnn_dynamics(edm_sd, t, z, nm, em, ctx)
+    d = EGNNDynamics(device=DEV)
+    d.load_reference_state_dict(edm_sd)
+    for rn in (1, 2, 3, 0):
+        d.set_option(_lib.OPT_GEMM_RN, rn)
+        ok, err, sc = close(d(t.to(DEV), z.to(DEV), nm.to(DEV), em.to(DEV), ctx.to(DEV)), ref)
+        assert ok, (rn, err, sc)
+    with pytest.raises(_lib.McgError):
+        d.set_option(_lib.OPT_GEMM_RN, 7)
+    with pytest.raises(_lib.McgError):
+        d.set_option(99, 1)
+    d.set_precision("f32x6")
+    for x6_gemm, rn in ((0, 0), (1, 1), (1, 3), (1, 0)):
+        d.set_option(_lib.OPT_X6_GEMM, x6_gemm)
+        d.set_option(_lib.OPT_GEMM_X6_RN, rn)
+        ok, err, sc = close(d(t.to(DEV), z.to(DEV), nm.to(DEV), em.to(DEV), ctx.to(DEV)), ref)
+        assert ok, (x6_gemm, rn, err, sc)
+    d.set_precision("f32")
+    plan = d.plan(sizes, N)
+    us = np.zeros(4, dtype=np.float32)
+    zt, ct, tt = z.to(DEV), ctx.to(DEV), t.reshape(-1).to(DEV)
+    out = torch.empty_like(zt)
+    _lib.check(_lib.lib().mcg_bench_edge_incall(d.handle, plan.handle, _lib.dptr(tt), _lib.dptr(zt), _lib.dptr(ct), _lib.dptr(out), 2,
+                                                us.ctypes.data, _lib.current_stream_ptr(DEV)), "mcg_bench_edge_incall")
+    assert int(us[2]) == 2 * 18 * plan.n_ranges and int(us[3]) == 2 * 9 * plan.n_ranges
+    assert 1.0 < float(us[0]) < 1000.0 and 1.0 < float(us[1]) < 1000.0          # microseconds per edge launch
+    ok, err, sc = close(out, ref)                                                 # the timed calls computed the real thing
+    assert ok, (err, sc)
+    ok, err, sc = close(d.run(plan, tt, zt, ct), ref)                             # and the plan still replays its graph
+    assert ok, (err, sc)
+
+
 def test_dynamics_full_gain_weights_vs_oracle():
     """Unit-gain synthetic weights (messages / aggregates are O(1), so every operand of the node
     MLP carries weight in the result) on a ragged batch, against the oracle."""
