@@ -212,6 +212,18 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
     return MCG_OK;
 }
 
+// SIMDs of the current device (4 per compute unit), queried once
+static long mcg_simd_count() {
+    static long n = 0;
+    if (n == 0) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipGetLastError();
+        n = 4L * (cus > 0 ? cus : 256);
+    }
+    return n;
+}
+
 // `side` (optional): plan whose pending coordinate update rides along as the launch's side job (fp32 kernels only).
 // `rows16` > 0: the 16-row wave-tile kernel with that many column tiles per wave; `a2_rows`: two-row gather of A2.
 int gemm(const float* A1, int lda1, int K1, const float* A2, int lda2, int K2, const float* Bp, const float* bias,
@@ -227,9 +239,16 @@ int gemm(const float* A1, int lda1, int K1, const float* A2, int lda2, int K2, c
     }
     if (rows16 > 0 && !Bp16 && !Bp16x3) {
         g.a2_rows = a2_rows; g.a2_nsum = a2_nsum;
+        // Small batches: narrower wave tiles (1 or 2 column tiles) as long as every wave still gets a SIMD of its own -
+        // these launches are one serial MFMA chain per wave, and a third of the chain is a third of the latency
+        // (4 molecules of 19 atoms: W3 18.6 -> ~9 us).  Same k order per output element: bit-identical results.
+        int rn = rows16;
+        const long rt = (M + 15) / 16;
+        for (int cand : {1, 2, 3})
+            if (cand < rows16 && rt * ((n_tiles + cand - 1) / cand) <= mcg_simd_count()) { rn = cand; break; }
         // 16-row wave tiles while they fit one wave per SIMD (972 waves at config 2), 32-row ones beyond
-        const long w16 = (long)((M + 15) / 16) * ((n_tiles + rows16 - 1) / rows16);
-        MCG_HIP(mcg_gemm16_launch(g, rows16, s, w16 <= 1280 ? 1 : 2));
+        const long w16 = rt * ((n_tiles + rn - 1) / rn);
+        MCG_HIP(mcg_gemm16_launch(g, rn, s, w16 <= 1280 ? 1 : 2));
         return MCG_OK;
     }
     if (Bp16x3) {            // f32x6: three-part operands on the bf16 pipe, fp32-accurate
@@ -241,6 +260,10 @@ int gemm(const float* A1, int lda1, int K1, const float* A2, int lda2, int K2, c
     MCG_HIP(mcg_gemm_launch(g, s, Bp16 != nullptr, opt ? opt->gemm_rn : 0));
     return MCG_OK;
 }
+
+// First-layer GEMM (N = 864): the 32-row kernel from ~900 atoms on (14.2 vs 14.8 us at configs[1]); below that the
+// 16-row kernel with as few column tiles per wave as still give every wave its own SIMD (gemm() picks 1 .. 6)
+static int pab_rows16(int M) { return (long)((M + 15) / 16) * ((2 * NT + 2) / 3) <= mcg_simd_count() ? 6 : 0; }
 
 // pending coordinate update (workgroup-level sums in pl->Ux) applied by a stand-alone launch
 int apply_pending_x(mcg_plan* pl, hipStream_t s) {
@@ -264,7 +287,7 @@ int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s, bool keep
     //  GEMM kernels have no side job: apply it first)
     if (!f32) { if (int e = apply_pending_x(pl, s)) return e; }
     if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
-                     MCG_ACT_NONE, s, lp ? E.pab_Bp16 : nullptr, x6g ? E.pab_Bp16x3 : nullptr, pl, 0, nullptr, 2, m)) return e;
+                     MCG_ACT_NONE, s, lp ? E.pab_Bp16 : nullptr, x6g ? E.pab_Bp16x3 : nullptr, pl, pab_rows16(M), nullptr, 2, m)) return e;
     if (int e = apply_pending_x(pl, s)) return e;              // (only if the GEMM above could not carry it)
     if (int e = run_edge(pl, E, false, pl->P, s, lp, m->x6, wgc)) return e;
     const int4* gather = nullptr;
@@ -295,8 +318,8 @@ int run_equiv(const mcg_egnn* m, mcg_plan* pl, int block, hipStream_t s) {
     const int M = pl->M;
     const bool wgc = edge_wgc(m, pl);
     if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
-                     MCG_ACT_NONE, s, m->bf16 ? E.pab_Bp16 : nullptr, (m->x6 && m->x6_gemm) ? E.pab_Bp16x3 : nullptr, nullptr, 0,
-                     nullptr, 2, m)) return e;
+                     MCG_ACT_NONE, s, m->bf16 ? E.pab_Bp16 : nullptr, (m->x6 && m->x6_gemm) ? E.pab_Bp16x3 : nullptr, nullptr,
+                     pab_rows16(M), nullptr, 2, m)) return e;
     if (int e = run_edge(pl, E, true, pl->Px, s, m->bf16, m->x6, wgc)) return e;
     if (wgc) {
         pl->x_pending = true;          // applied by the next launch that can carry it (next block's first GEMM / k_output)

@@ -773,7 +773,7 @@ __global__ __launch_bounds__(256) void mcg_gemm16_kernel(McgGemmArgs p) {
     }
 }
 
-// launcher: rn in {2, 3, 6} column tiles and mr in {1, 2} row tiles of 16 per wave; the optional side job adds
+// launcher: rn in {1, 2, 3, 6} column tiles and mr in {1, 2} row tiles of 16 per wave; the optional side job adds
 // ceil(side_M * 4 / 256) workgroups.
 static inline hipError_t mcg_gemm16_launch(McgGemmArgs a, int rn, hipStream_t s, int mr = 1) {
     if (a.M <= 0) return hipSuccess;
@@ -789,6 +789,7 @@ static inline hipError_t mcg_gemm16_launch(McgGemmArgs a, int rn, hipStream_t s,
     if (mr == 2) { if (rn == 3) MCG_G16(3, 2); else MCG_G16(2, 2); }
     else if (rn == 6) MCG_G16(6, 1);
     else if (rn == 3) MCG_G16(3, 1);
+    else if (rn == 1) MCG_G16(1, 1);
     else MCG_G16(2, 1);
 #undef MCG_G16
     return hipGetLastError();
