@@ -2,7 +2,7 @@
 #pragma once
 #include "../../include/mlconfgen_hip.h"
 
-// accessors of the opaque plan (defined in mcg_egnn.hip)
+// accessors of the opaque plan (defined in mcg_egnn_plan.hip)
 int mcg_plan_B(const mcg_plan* p);
 int mcg_plan_N(const mcg_plan* p);
 const int* mcg_plan_n_nodes(const mcg_plan* p);   // device pointer

@@ -40,7 +40,7 @@ struct McgGemmArgs {
     int act;
     // --- mcg_gemm16_kernel only (value-initialise the struct: zero = unused) ---
     const int4* a2_rows;                    // optional: row r of segment 2 is the SUM of the first a2_nsum (2..4) of rows
-    int a2_nsum;                            // a2_rows[r].x .y .z .w of A2: the workgroup-level partial-sum slots of an atom (mcg_egnn.hip)
+    int a2_nsum;                            // a2_rows[r].x .y .z .w of A2: the workgroup-level partial-sum slots of an atom (mcg_plan_host.cpp)
     // side job run by the blocks beyond the GEMM's own grid (independent data, saves a launch):
     // x[v][0..2] += (side_u[s.x] + side_u[s.y] + side_u[s.z] + side_u[s.w]) / 100 - the coordinate update of the previous block (egnn.py:128-148)
     const float* side_u; const int4* side_slots; float* side_x; int side_M;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void mcg_gemm_bf16_kernel(McgGemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// "f32x6" variant: fp32-accurate GEMM on the bf16 matrix pipe (see k_edge_bf16_w64 in mcg_egnn.hip).  Every fp32
+// "f32x6" variant: fp32-accurate GEMM on the bf16 matrix pipe (see k_edge_bf16_w64 in mcg_edge_bf16.hip).  Every fp32
 // operand is the exact sum of three bf16 parts; the six partial products of weight >= 2^-16 are accumulated in fp32.
 // The weights come pre-split ("B-pack16x3": [k-block][part][n-tile][lane][8], host side below).  The activation
 // rows are split ONCE per workgroup: the four waves (which share the same 32 rows) each load and split a quarter

@@ -1,6 +1,6 @@
 // Error reporting + the stand-alone EGNN aggregate kernel (gate x mask x segmented per-node sum,
 // reference egnn.py:49-51,59-64,418-437) kept as its own HBM-roofline probe: in the production
-// path the aggregation is fused into the edge-MLP epilogue (mcg_egnn.hip) and m_ij never exists.
+// path the aggregation is fused into the edge-MLP epilogue (mcg_edge_exact.hip) and m_ij never exists.
 #include "mcg_common.h"
 #include "mcg_api_internal.h"
 
