@@ -570,7 +570,7 @@ def test_adj_mat_seer_b64_vs_oracle(gcn, gcn_sd):
     assert n_diff <= int((~safe).sum())
 
 
-@pytest.mark.parametrize("name", ["e2e_T20_b4n19.npz", "e2e_T8_b8n27.npz"])
+@pytest.mark.parametrize("name", ["e2e_T20_b4n19.npz", "e2e_T8_b8n27.npz", "e2e_merge_T10_L10.npz"])
 def test_generate_path_end_to_end_vs_reference_golden(sampler_factory, gcn, gcn_sd, name):
     """north_star's parity clause on the COMPOSED path (conformer_generator.py:330-366; mol_utils.py:146-194,210-211):
     HIP sampler under the reference's recorded noise tape -> mcg_handoff -> mcg_gcn_forward -> bond argmax ->
@@ -588,7 +588,13 @@ def test_generate_path_end_to_end_vs_reference_golden(sampler_factory, gcn, gcn_
     nm = g["node_mask"]
     gm = sampler_factory(int(g["T"]), g, "f32")
     gm.noise_fn = TapeNoise(g["noise"], DEV)
-    x, h = gm(nm.to(DEV), edge_mask_of(nm).to(DEV), g["context"].to(DEV), 0)
+    merge = "route" in g            # the fragment-merge route of edm_samples (conformer_generator.py:231-240)
+    if merge:
+        x, h = gm.merge_fragments(nm.to(DEV), edge_mask_of(nm).to(DEV), g["fixed_mask"], g["context"].to(DEV), g["z_known"],
+                                  int(g["diffusion_level"]), int(g["resample_steps"]), int(g["blend_power"]))
+    else:
+        x, h = gm(nm.to(DEV), edge_mask_of(nm).to(DEV), g["context"].to(DEV), 0)
+    assert gm.noise_fn.pos == g["noise"].numel()
     gm.noise_fn = None
     assert torch.equal(h.cpu().to(torch.int64), g["h"].to(torch.int64))                       # atom types exact
     vx = traj_violation(x.cpu().unsqueeze(0), g["x"].unsqueeze(0), split=None)
@@ -633,7 +639,11 @@ def test_generate_path_end_to_end_vs_reference_golden(sampler_factory, gcn, gcn_
     from oracle import diffusion_oracle as DO
     from oracle import gcn_oracle as GO
     orc = DO.SamplerOracle(sd_for(g), int(g["T"]), noise_fn=TapeNoise(g["noise"]))
-    xo, ho = orc.forward(nm, edge_mask_of(nm), g["context"], 0)
+    if merge:
+        xo, ho = orc.merge_fragments(nm, edge_mask_of(nm), g["fixed_mask"], g["context"], g["z_known"], int(g["diffusion_level"]),
+                                     int(g["resample_steps"]), int(g["blend_power"]))
+    else:
+        xo, ho = orc.forward(nm, edge_mask_of(nm), g["context"], 0)
     elo, dmo, amo = HO.adj_mat_seer_input(xo, ho, n_nodes)
     lo = GO.adj_mat_seer(gcn_sd, elo, dmo, amo)
     assert torch.equal(el.cpu(), elo) and torch.equal(am.cpu(), amo)

@@ -128,7 +128,7 @@ def test_adj_mat_seer(gcn_sd):
     assert torch.equal(logits, logits.transpose(1, 2))
 
 
-@pytest.mark.parametrize("name", ["e2e_T20_b4n19.npz", "e2e_T8_b8n27.npz"])
+@pytest.mark.parametrize("name", ["e2e_T20_b4n19.npz", "e2e_T8_b8n27.npz", "e2e_merge_T10_L10.npz"])
 def test_composed_path_oracle_vs_reference(name, gcn_sd):
     """The COMPOSED path of generate_conformers (conformer_generator.py:330-366): sampler (recorded noise tape) ->
     hand-off tensors -> AdjMatSeer -> bond argmax.  The fixture holds what the reference's own EquivariantDiffusion and
@@ -136,7 +136,11 @@ def test_composed_path_oracle_vs_reference(name, gcn_sd):
     g = load_golden(name)
     nm = g["node_mask"]
     orc = DO.SamplerOracle(sd_for(g), int(g["T"]), noise_fn=TapeNoise(g["noise"]))
-    x, h = orc.forward(nm, edge_mask_of(nm), g["context"], 0)
+    if "route" in g:            # the fragment-merge route of edm_samples (conformer_generator.py:231-240)
+        x, h = orc.merge_fragments(nm, edge_mask_of(nm), g["fixed_mask"], g["context"], g["z_known"], int(g["diffusion_level"]),
+                                   int(g["resample_steps"]), int(g["blend_power"]))
+    else:
+        x, h = orc.forward(nm, edge_mask_of(nm), g["context"], 0)
     assert traj_violation(x.unsqueeze(0), g["x"].unsqueeze(0), split=None) <= 1.0
     assert torch.equal(h.to(torch.int64), g["h"].to(torch.int64))
     el, dm, am = HO.adj_mat_seer_input(x, h, g["n_nodes"])

@@ -245,6 +245,9 @@ def main():
     save("merge_T10_L10.npz", node_mask=nm, context=ctx, z_known=zk, fixed_mask=fixed, noise=tape.flat(),
          z_trace=torch.stack(trace), x=x, h=h, T=10, diffusion_level=10, resample_steps=1, blend_power=3,
          weight_seed=1234, weight_recipe=np.array("v2"))
+    e2e_runs["e2e_merge_T10_L10.npz"] = dict(node_mask=nm, context=ctx, z_known=zk, fixed_mask=fixed, noise=tape.flat(), x=x, h=h, T=10,
+                                             diffusion_level=10, resample_steps=1, blend_power=3, weight_seed=1234,
+                                             weight_recipe=np.array("v2"), route=np.array("merge_fragments"))
     # the level > T failure mode (quirk H5)
     try:
         gm.merge_fragments(nm, em, fixed, ctx, zk, diffusion_level=50)
