@@ -223,6 +223,7 @@ def timed_passes(gen, ctx, n_total, n_atoms, variance, frag_kw, steps, warmup, f
     """`steps` timed calls of the public sharded path after `warmup` untimed ones.
     Returns (elapsed seconds on this rank, mean sampler ms per pass, whether EVERY coordinate this rank generated in the
     timed passes is finite - checked after the clock stops, last valid fraction)."""
+    from ml_conformer_generator_amd.conformer_generator import HAVE_RDKIT     # (MMFF94 runs only where RDKit exists)
     sampler_ms = []
     kept = []
 
@@ -232,10 +233,10 @@ def timed_passes(gen, ctx, n_total, n_atoms, variance, frag_kw, steps, warmup, f
         torch.default_generator.manual_seed(seed)
         if ref_conformer is not None:
             mols = gen.generate_conformers_sharded(reference_conformer=ref_conformer, variance=variance, n_samples=n_total,
-                                                   seed=seed, **frag_kw)
+                                                   seed=seed, optimise_geometry=HAVE_RDKIT, **frag_kw)
         else:
             mols = gen.generate_conformers_sharded(reference_context=ctx, n_atoms=n_atoms, variance=variance,
-                                                   n_samples=n_total, seed=seed, **frag_kw)
+                                                   n_samples=n_total, seed=seed, optimise_geometry=HAVE_RDKIT, **frag_kw)
         torch.cuda.synchronize(gen.device)
         sampler_ms.append(gen._timing["sampler_start"].elapsed_time(gen._timing["sampler_end"]))
         if gen.last_batch is not None:
