@@ -56,7 +56,14 @@ int mcg_egnn_set_precision(mcg_egnn* m, int mode);
  *   MCG_OPT_GEMM_RN     [0]  wave tile width (column tiles) of the 32-row node GEMM kernel: 0 = cost model, 1..3
  *   MCG_OPT_GEMM_X6_RN  [0]  same for the split-operand GEMM kernel */
 enum { MCG_OPT_X6_GEMM = 1, MCG_OPT_GEMM_RN = 2, MCG_OPT_GEMM_X6_RN = 3 };
+/* Both setters may be called at any time between denoiser calls: a plan that has already captured its launches as a HIP
+ * graph re-captures on its next call (the graph is keyed by the model's option epoch). */
 int mcg_egnn_set_option(mcg_egnn* m, int option, int value);
+
+/* Measurement / test hook: node and GCN GEMM launches ISSUED (plainly or into a graph capture) by this process since the
+ * last reset, counts_host[family * 8 + rn] with family 0 = 32-row fp32 kernel, 1 = 32-row bf16 kernel, 2 = 16-row-tile fp32
+ * kernel, 3 = split-operand kernel and rn = column tiles per wave - how a test sees that an option changed launch shapes. */
+int mcg_debug_gemm_launches(int64_t* counts_host, int reset);
 
 /* ---- Batch plan.  Replaces the per-call `get_adj_matrix` edge-list rebuild (egnn.py:475,515-541)
  * and the node/edge masks (mol_utils.py:226-252): node_mask[b] is the prefix of n_nodes_host[b]
@@ -164,12 +171,31 @@ void mcg_gcn_destroy(mcg_gcn* g);
 int mcg_gcn_forward(mcg_gcn* g, const int64_t* elements, const float* dist_mat, const float* adj_mat, float* logits,
                     int8_t* bond, int B, void* stream);
 int mcg_gcn_check(mcg_gcn* g);
-/* EDM -> GCN hand-off without RDKit (replaces samples_to_rdkit_mol + prepare_adj_mat_seer_input,
- * utils/mol_utils.py:18-57,146-194, for the tensor part): elements[B,42] int64 (atomic numbers, 0 padded),
- * dist_mat[B,42,42] (distances + I), adj_mat[B,42,42] ({0,1} covalent-radius connectivity + I) from
- * x[B,N,3], h[B,N,8] one-hot and n_nodes[B] (device int32).  Atoms keep their generation order. */
+/* EDM -> GCN hand-off (replaces samples_to_rdkit_mol + prepare_adj_mat_seer_input, utils/mol_utils.py:18-57,146-194,
+ * for the tensor part): elements[B,42] int64 (atomic numbers, 0 padded), dist_mat[B,42,42] (distances + I),
+ * adj_mat[B,42,42] ({0,1} covalent-radius connectivity + I) from x[B,N,3], h[B,N,8] one-hot and n_nodes[B] (device
+ * int32).  Atoms keep their generation order. */
 int mcg_handoff(const float* x, const float* h, const int32_t* n_nodes_dev, int B, int N, float cov_factor,
-                int64_t* elements, float* dist_mat, float* adj_mat, void* stream);   /* non-zero if an element id outside [0,36) was seen */
+                int64_t* elements, float* dist_mat, float* adj_mat, void* stream);
+/* The same with the two RDKit-owned decisions of the reference open to the caller (`canonicalise`,
+ * utils/mol_utils.py:110-126: DetermineConnectivity + `_smilesAtomOutputOrder` + RenumberAtoms; the MolGraph adjacency
+ * of `prepare_adj_mat_seer_input`, :146-194).  AdjMatSeer is NOT permutation-equivariant (nodes_coord_fc is a dense layer
+ * over the position index, adj_mat_seer.py:135-138), so a checkpoint trained on canonical-SMILES order needs that order:
+ *   order[B,42] int32 (device; NULL = generation order): order[b][p] = generation index of the atom placed at
+ *                position p - the argument of `Chem.RenumberAtoms(mol, order)`; the first n_nodes[b] entries of row b must
+ *                be a permutation of 0..n_nodes[b]-1 (out-of-range entries are clamped and reported through
+ *                bad_order_flag), the rest is ignored;
+ *   conn_in[B,42,42] uint8 (device; NULL = covalent-radius rule d < cov_factor*(r_i + r_j)): symmetric {0,1}
+ *                1-order connectivity in GENERATION order (what DetermineConnectivity perceives before renumbering);
+ *                the diagonal is ignored, +I is added here; it is permuted with the atoms;
+ *   x_out[B,N,3] (NULL = not wanted; may not alias x): the coordinates in the order of the GCN input, zero padded -
+ *                the reference's `canonicalised_samples`, whose order the bond write-back and the returned
+ *                molecules follow (conformer_generator.py:357-366);
+ *   bad_order_flag (device int32, NULL = not wanted): set to 1 if an order entry was out of range; never cleared here.
+ * elements / dist_mat / adj_mat come out in the permuted order. */
+int mcg_handoff_ex(const float* x, const float* h, const int32_t* n_nodes_dev, int B, int N, float cov_factor,
+                   const int32_t* order, const uint8_t* conn_in, int64_t* elements, float* dist_mat, float* adj_mat,
+                   float* x_out, int32_t* bad_order_flag, void* stream);
 
 /* Bond write-back + validity pre-filter behind the GCN (replaces the tensor half of `redefine_bonds`,
  * utils/mol_utils.py:197-223, and stands in for `standardize_mol(...) is not None`, conformer_generator.py:362-366 /

@@ -24,6 +24,7 @@ SIGNATURES: Dict[str, tuple] = {
     "mcg_egnn_destroy": (None, [_vp]),
     "mcg_egnn_set_precision": (_i, [_vp, _i]),
     "mcg_egnn_set_option": (_i, [_vp, _i, _i]),
+    "mcg_debug_gemm_launches": (_i, [_vp, _i]),
     "mcg_plan_create": (_i, [_i, _i, _vp, _i, _pp]),
     "mcg_plan_create_ex": (_i, [_i, _i, _vp, _vp, _pp]),
     "mcg_plan_destroy": (None, [_vp]),
@@ -48,6 +49,7 @@ SIGNATURES: Dict[str, tuple] = {
     "mcg_gcn_check": (_i, [_vp]),
     "mcg_shape_tanimoto": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp]),
     "mcg_handoff": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "mcg_handoff_ex": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mcg_bond_writeback": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "mcg_ifm_merge": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
 }

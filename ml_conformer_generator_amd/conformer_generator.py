@@ -5,8 +5,13 @@ Same constructor kwargs, method names, argument order and errors as
 forced by the scope of this build:
   * `device` must be a ROCm GPU (default cuda:0): there is no CPU path;
   * `edm_weights` / `adj_mat_seer_weights` may also be an in-memory state dict;
-  * the RDKit-owned stages BEFORE the GCN are replaced by the native hand-off of `handoff.py`
-    (two HIP launches);
+  * the RDKit-owned stages BEFORE the GCN run as the native hand-off of `handoff.py` (one HIP launch).  Its two
+    RDKit-owned decisions - canonical-SMILES atom order and 1-order connectivity (`canonicalise`, mol_utils.py:110-126) -
+    are inputs of that launch, supplied by `atom_order_provider`: "auto" (default) = RDKit's where RDKit imports
+    (`rdkit_order.rdkit_provider`, the reference's own call sequence), else the labelled substitutes (generation order,
+    covalent-radius rule); a callable = the caller's own; None = the substitutes.  AdjMatSeer depends on the atom
+    order, so with a trained checkpoint the substitutes predict different bonds than the reference.  The returned
+    molecules carry their atoms in the order the GCN saw them, like the reference's `canonicalised_samples`;
   * RETURN TYPE: where RDKit imports, `generate_conformers` returns `List[Chem.Mol]` like the
     reference - the HIP path's molecules go through `rdkit_finish.finish` (the reference's
     `standardize_mol` sequence incl. MMFF when `optimise_geometry`; untested offline, RDKit is
@@ -18,6 +23,7 @@ forced by the scope of this build:
 """
 from __future__ import annotations
 
+import time
 import warnings
 from typing import List, Optional, Union
 
@@ -30,6 +36,7 @@ from .config import (ATOM_DECODER, CONTEXT_NORMS, DIMENSION, MAX_N_NODES, MIN_N_
 from .egnn import EGNNDynamics
 from .equivariant_diffusion import EquivariantDiffusion, PredefinedNoiseSchedule
 from . import distributed as mcg_dist
+from . import rdkit_order
 from .handoff import (GeneratedMolecule, assemble_molecules, bond_writeback_hip, molecules_from_tensors,
                       prepare_adj_mat_seer_input_hip)
 from .mol_utils import (get_context_shape, ifm_get_xh_from_fragment, ifm_merge_hip,
@@ -78,7 +85,7 @@ class MLConformerGenerator(torch.nn.Module):
                  context_norms: dict = CONTEXT_NORMS, atom_decoder: dict = ATOM_DECODER,
                  edm_weights: Union[str, dict] = "./edm_moi_chembl_15_39.pt",
                  adj_mat_seer_weights: Union[str, dict] = "./adj_mat_seer_chembl_15_39.pt",
-                 compute_dtype: str = "f32"):
+                 compute_dtype: str = "f32", atom_order_provider="auto"):
         super().__init__()
         _lib.lib()       # fail loudly if the HIP library is not built
         device = torch.device("cuda:0" if device is None else device)
@@ -104,9 +111,12 @@ class MLConformerGenerator(torch.nn.Module):
         self.generative_model = generative_model
         self.set_diffusion_steps(diffusion_steps)
         self.adj_mat_seer = adj_mat_seer
+        # (atomic_numbers, coords[n,3]) -> (order, connectivity) | None per molecule: see rdkit_order.py
+        self.atom_order_provider = rdkit_order.default_provider() if atom_order_provider == "auto" else atom_order_provider
         self.last_batch = None       # tensors of the most recent generation (x, h, n_nodes, bond)
         self.last_valid_fraction = None   # share of the last batch that passed the validity proxy
         self.last_noise_seed = None       # device-generator seed of the last sharded call on this rank
+        self.last_host_assembly_ms = None # host time of the last sharded call's D2H + molecule records
         self._timing = None          # bench.py: {"sampler_start", "sampler_end"} events recorded around the sampler
 
     def set_diffusion_steps(self, diffusion_steps: int) -> None:
@@ -164,7 +174,9 @@ class MLConformerGenerator(torch.nn.Module):
     def edm_samples(self, reference_context: torch.Tensor, n_samples: int = 100, max_n_nodes: int = 32,
                     min_n_nodes: int = 25, resample_steps: int = 0, fixed_fragment=None,
                     inertial_fragment_matching: bool = True, blend_power: int = 3, ifm_diffusion_level: int = 50):
-        """Samples without bonds (conformer_generator.py:125-266) as GeneratedMolecule records."""
+        """Samples without bonds (conformer_generator.py:125-266): `List[Chem.Mol]` through `samples_to_rdkit_mol`'s XYZ
+        route where RDKit imports (`rdkit_finish.samples`, untested offline), else `GeneratedMolecule` records.  Atoms in
+        generation order, as in the reference (canonicalisation happens later, in `generate_conformers`)."""
         x, h, node_mask = self.edm_tensors(reference_context, n_samples, max_n_nodes, min_n_nodes, resample_steps,
                                            fixed_fragment, inertial_fragment_matching, blend_power,
                                            ifm_diffusion_level)
@@ -174,6 +186,9 @@ class MLConformerGenerator(torch.nn.Module):
         mols = assemble_molecules(x, el, no_bonds, n_nodes)
         for m in mols:
             m.valid = True          # no bonds yet: the connectivity proxy does not apply
+        if HAVE_RDKIT:
+            from . import rdkit_finish
+            return rdkit_finish.samples(mols)
         return mols
 
     # ------------------------------------------------------------------ full pipeline
@@ -217,11 +232,18 @@ class MLConformerGenerator(torch.nn.Module):
             inertial_fragment_matching=inertial_fragment_matching, blend_power=blend_power,
             ifm_diffusion_level=ifm_diffusion_level, sizes=sizes)
         n_nodes = node_mask.sum(1).reshape(-1).to(torch.long)
-        el, dm, am = prepare_adj_mat_seer_input_hip(x, h, n_nodes, D)
+        order = conn = built = None
+        if self.atom_order_provider is not None:          # host: RDKit's (or the caller's) order + connectivity
+            order, conn, built = rdkit_order.batch_order_and_connectivity(self.atom_order_provider, x, h, n_nodes)
+        # atoms, distances, connectivity AND coordinates come out in the order the GCN sees (canonicalised_samples)
+        el, dm, am, x_out = prepare_adj_mat_seer_input_hip(x, h, n_nodes, D, order=order, connectivity=conn,
+                                                           with_coords=True)
         bond = self.adj_mat_seer.bond_orders(el, dm, am)
         sym, valid = bond_writeback_hip(bond, el, n_nodes)
-        self.last_batch = dict(x=x, h=h, n_nodes=n_nodes, elements=el, bond=bond)
-        return dict(x=x, elements=el.to(torch.int8), bond=sym, n_nodes=n_nodes.to(torch.int32),
+        if built is not None and not all(built):          # `MolFromXYZBlock` returned None: the reference drops it
+            valid = valid & torch.tensor(built, dtype=torch.bool, device=valid.device)
+        self.last_batch = dict(x=x, h=h, n_nodes=n_nodes, elements=el, bond=bond, x_ordered=x_out, order=order)
+        return dict(x=x_out, elements=el.to(torch.int8), bond=sym, n_nodes=n_nodes.to(torch.int32),
                     valid=valid.to(torch.uint8))
 
     @torch.no_grad()
@@ -246,7 +268,8 @@ class MLConformerGenerator(torch.nn.Module):
                                     reference_context: torch.Tensor = None, n_atoms: int = None,
                                     optimise_geometry: bool = True, resample_steps: int = 0, fixed_fragment=None,
                                     inertial_fragment_matching: bool = True, blend_power: int = 3,
-                                    ifm_diffusion_level: int = 50, group=None, seed: Optional[int] = None) -> List:
+                                    ifm_diffusion_level: int = 50, group=None, seed: Optional[int] = None,
+                                    gather: str = "all") -> List:
         """`generate_conformers` for `n_samples` molecules in TOTAL, sharded over the ranks of the initialised
         `torch.distributed` group (one process per GPU, each with its own generator instance / weight replica;
         SURVEY.md section 8e).  The global size vector is drawn once on rank 0 and broadcast, rank r generates
@@ -254,7 +277,11 @@ class MLConformerGenerator(torch.nn.Module):
         end gives every rank the full batch, in sample order.  `seed`: per-rank noise seed `seed + rank` for the
         device generator; None (default) = a base seed drawn on rank 0 and broadcast, so that ranks NEVER share a noise
         stream (every process starts its device generator from the same constant).  A rank whose shard fails makes
-        every rank raise `distributed.ShardError`.  Without an initialised group this is `generate_conformers`."""
+        every rank raise `distributed.ShardError`.  `gather="rank0"`: only rank 0 of the group receives (and returns) the
+        whole batch - one `gather` instead of the all-gather - and every other rank returns its own shard's molecules.
+        Without an initialised group this is `generate_conformers`."""
+        if gather not in ("all", "rank0"):
+            raise ValueError("gather must be 'all' or 'rank0'")
         ref_context, ref_n_atoms = self._reference_context(reference_conformer, reference_context, n_atoms)
         lo_n = max(ref_n_atoms - variance, self.min_n_nodes)
         hi_n = min(ref_n_atoms + variance, self.max_n_nodes)
@@ -271,8 +298,10 @@ class MLConformerGenerator(torch.nn.Module):
 
         _, res = mcg_dist.sharded_generate(
             n_samples, lambda: mcg_dist.draw_global_sizes(n_samples, lo_n, hi_n, group), run_shard, group=group,
-            seed=seed, seed_fn=seed_device)
+            seed=seed, seed_fn=seed_device, gather_dst=0 if gather == "rank0" else None)
+        t0 = time.perf_counter()
         mols = molecules_from_tensors(res["x"], res["elements"], res["bond"], res["n_nodes"], res["valid"])
+        self.last_host_assembly_ms = (time.perf_counter() - t0) * 1e3      # D2H of the gathered tensors + record views
         kept, self.last_valid_fraction = _finish(mols, optimise_geometry)
         return kept
 

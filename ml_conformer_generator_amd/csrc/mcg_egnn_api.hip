@@ -4,6 +4,7 @@
 #include "mcg_gemm.h"
 #include "mcg_egnn_internal.h"
 
+#include <atomic>
 #include <cstring>
 #include <utility>
 
@@ -212,16 +213,21 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
     return MCG_OK;
 }
 
-// SIMDs of the current device (4 per compute unit), queried once
+// SIMDs of the CURRENT device (4 per compute unit), queried once per device: one process may drive several devices
 static long mcg_simd_count() {
-    static long n = 0;
-    if (n == 0) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    static std::atomic<long> n[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 1024; }
+    const int slot = dev >= 0 && dev < 64 ? dev : 0;
+    long v = n[slot].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         (void)hipGetLastError();
-        n = 4L * (cus > 0 ? cus : 256);
+        v = 4L * (cus > 0 ? cus : 256);
+        n[slot].store(v, std::memory_order_relaxed);
     }
-    return n;
+    return v;
 }
 
 // `side` (optional): plan whose pending coordinate update rides along as the launch's side job (fp32 kernels only).
@@ -396,7 +402,7 @@ int mcg_egnn_dynamics(const mcg_egnn* m, mcg_plan* pl, const float* t, const flo
         if (out != out_user) MCG_HIP(hipMemcpyAsync(out_user, out, n_xh * sizeof(float), hipMemcpyDeviceToDevice, s));
         return MCG_OK;
     };
-    const void* key[5] = {xh, context, out, (const void*)(size_t)m->uid, (const void*)(size_t)(m->bf16 ? 1 : m->x6 ? 2 : 0)};
+    const void* key[5] = {xh, context, out, (const void*)(size_t)m->uid, (const void*)(((size_t)m->opt_epoch << 8) | (size_t)(m->bf16 ? 1 : m->x6 ? 2 : 0))};
     if (pl->graph_exec && memcmp(key, pl->g_key, sizeof(key)) == 0) {
         MCG_HIP(hipGraphLaunch(pl->graph_exec, s));
         return finish();

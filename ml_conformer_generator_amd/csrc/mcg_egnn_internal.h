@@ -90,6 +90,8 @@ struct mcg_egnn {
     // options (mcg_egnn_set_option)
     bool x6_gemm = true;        // f32x6 mode: node-side GEMMs on the split-operand kernel too
     int gemm_rn = 0, gemm_x6_rn = 0;   // wave tile width of the node GEMMs (0 = the launcher's cost model)
+    uint32_t opt_epoch = 0;     // bumped by mcg_egnn_set_precision / mcg_egnn_set_option: part of the captured graph's key,
+                                // so a plan that already captured its launches re-captures after a change
     float *emb_wT = nullptr, *emb_b = nullptr, *out_w = nullptr, *out_b = nullptr;
     std::vector<EdgeLayer> gcl_edge;   // 2 per block
     std::vector<NodeLayer> gcl_node;   // 2 per block
@@ -131,7 +133,7 @@ struct mcg_plan {
     float* t_buf = nullptr;                 // fixed device copy of t[B] read by the captured graph
     hipStream_t cap_stream = nullptr;       // capture happens here (the caller's stream may be the null stream)
     hipGraphExec_t graph_exec = nullptr;
-    const void* g_key[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // xh, context, out, model uid, precision mode
+    const void* g_key[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // xh, context, out, model uid, precision mode | option epoch << 8
     int graph_failed = 0;
     // Callers whose tensors move between calls (the reference's own sampler loop allocates a fresh xh / out
     // every step) would force a re-capture per call: after the second key change the graph is captured on

@@ -236,15 +236,16 @@ int mcg_egnn_set_precision(mcg_egnn* m, int mode) {
     if (mode < 0 || mode > 2) { mcg_set_error("mcg_egnn_set_precision: mode must be 0 (fp32), 1 (bf16) or 2 (f32x6)"); return MCG_ERR_ARG; }
     m->bf16 = mode == 1;
     m->x6 = mode == 2;
+    ++m->opt_epoch;
     return MCG_OK;
 }
 
 int mcg_egnn_set_option(mcg_egnn* m, int option, int value) {
     if (!m) return MCG_ERR_ARG;
     switch (option) {
-        case MCG_OPT_X6_GEMM: m->x6_gemm = value != 0; return MCG_OK;
-        case MCG_OPT_GEMM_RN: if (value >= 0 && value <= 3) { m->gemm_rn = value; return MCG_OK; } break;
-        case MCG_OPT_GEMM_X6_RN: if (value >= 0 && value <= 3) { m->gemm_x6_rn = value; return MCG_OK; } break;
+        case MCG_OPT_X6_GEMM: m->x6_gemm = value != 0; ++m->opt_epoch; return MCG_OK;
+        case MCG_OPT_GEMM_RN: if (value >= 0 && value <= 3) { m->gemm_rn = value; ++m->opt_epoch; return MCG_OK; } break;
+        case MCG_OPT_GEMM_X6_RN: if (value >= 0 && value <= 3) { m->gemm_x6_rn = value; ++m->opt_epoch; return MCG_OK; } break;
         default: break;
     }
     mcg_set_error("mcg_egnn_set_option: unknown option %d or value %d out of range", option, value);

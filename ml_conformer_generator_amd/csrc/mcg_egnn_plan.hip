@@ -145,16 +145,9 @@ static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, c
     else if (p->MT == 1) parts = p->n_mtiles < 3600 ? 1 : p->n_mtiles < 5200 ? 2 : p->n_mtiles < 14000 ? 3 : 4;
     else parts = p->n_mtiles >= 8192 ? 2 : 1;
     if (parts < 2 || B < 2 * parts || p->n_rows < 4096) return MCG_OK;
-    std::vector<long> cum(B + 1, 0);
-    for (int b = 0; b < B; ++b) cum[b + 1] = cum[b] + (long)n_nodes_host[b] * (n_nodes_host[b] > 0 ? n_nodes_host[b] - 1 : 0);
-    int b0 = 0;
-    for (int k = 0; k < parts; ++k) {
-        int b1 = B;
-        if (k + 1 < parts) {
-            const long target = cum[B] * (k + 1) / parts;
-            b1 = b0 + 1;
-            while (b1 < B && cum[b1] < target) ++b1;
-        }
+    const std::vector<int> cuts = mcg_plan_range_cuts(B, n_nodes_host, parts);     // host-only, sanitizer-covered
+    for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+        const int b0 = cuts[k], b1 = cuts[k + 1];
         mcg_plan* sub = nullptr;
         if (int e = plan_create_single(b1 - b0, N, n_nodes_host + b0, opts, &sub)) return e;
         p->subs.push_back(sub);
@@ -164,7 +157,6 @@ static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, c
         MCG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         p->streams.push_back(st);
         p->ev_join.push_back(ev);
-        b0 = b1;
     }
     MCG_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
     return MCG_OK;

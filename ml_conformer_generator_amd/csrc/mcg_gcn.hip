@@ -101,43 +101,62 @@ __global__ __launch_bounds__(256) void k_symm(const float* __restrict__ res, flo
 }
 
 // EDM -> GCN hand-off, one workgroup per molecule: atom types from the one-hot classes,
-// pairwise distances (+I, zero padded to 42) and covalent-radius 1-order connectivity (+I) - the three
-// tensors `prepare_adj_mat_seer_input` (mol_utils.py:146-194) builds through RDKit, without the
-// per-atom host loop.  Atoms keep their generation order (RDKit's canonical order is not reproducible).
+// pairwise distances (+I, zero padded to 42) and 1-order connectivity (+I) - the three tensors
+// `prepare_adj_mat_seer_input` (mol_utils.py:146-194) builds through RDKit, without the per-atom host loop.
+// `order` (may be NULL): order[b][p] = generation index of the atom that sits at position p of the GCN input - the
+// argument of `Chem.RenumberAtoms(mol, order)` in `canonicalise` (mol_utils.py:110-126); NULL = generation order.
+// `conn_in` (may be NULL): {0,1} connectivity in GENERATION order, i.e. what `DetermineConnectivity` perceives on the
+// un-renumbered molecule (:117); it is permuted like the atoms.  NULL = the covalent-radius rule.
+// `x_out` (may be NULL): the coordinates in the order of the GCN input (the reference's `canonicalised_samples`).
+// `bad` (may be NULL): set to 1 when an order entry is outside [0, n) (the entry is clamped).
 __global__ __launch_bounds__(256) void k_handoff(const float* __restrict__ x, const float* __restrict__ h,
                                                   const int* __restrict__ n_nodes, int N, float cov_factor,
+                                                  const int* __restrict__ order, const uint8_t* __restrict__ conn_in,
                                                   int64_t* __restrict__ elements, float* __restrict__ dist,
-                                                  float* __restrict__ adj) {
+                                                  float* __restrict__ adj, float* __restrict__ x_out,
+                                                  int* __restrict__ bad) {
     __shared__ float sx[D][3];
     __shared__ float srad[D];
-    __shared__ int sz[D];
+    __shared__ int ssrc[D];
     const int b = blockIdx.x;
-    const int n = min(n_nodes[b], D);
+    const int n = min(n_nodes[b], min(D, N));
     // class -> atomic number (config.py:20-29) and single-bond covalent radius (Cordero 2008)
     const int zt[8] = {6, 7, 8, 9, 15, 16, 17, 35};
     const float rt[8] = {0.76f, 0.71f, 0.66f, 0.57f, 1.07f, 1.05f, 1.02f, 1.20f};
     for (int i = threadIdx.x; i < D; i += 256) {
-        int z = 0; float r = 0.f; float px = 0.f, py = 0.f, pz = 0.f;
+        int z = 0; float r = 0.f; float px = 0.f, py = 0.f, pz = 0.f; int src = i;
         if (i < n) {
-            const float* hr = h + ((size_t)b * N + i) * 8;
+            if (order) {
+                src = order[(size_t)b * D + i];
+                if (src < 0 || src >= n) { if (bad) atomicExch(bad, 1); src = min(max(src, 0), n - 1); }
+            }
+            const float* hr = h + ((size_t)b * N + src) * 8;
             int best = 0; float bv = hr[0];
 #pragma unroll
             for (int k = 1; k < 8; ++k) if (hr[k] > bv) { bv = hr[k]; best = k; }    // argmax(one_hot) (mol_utils.py:41)
             z = zt[best]; r = rt[best];
-            const float* xr = x + ((size_t)b * N + i) * 3;
+            const float* xr = x + ((size_t)b * N + src) * 3;
             px = xr[0]; py = xr[1]; pz = xr[2];
         }
-        sz[i] = z; srad[i] = r; sx[i][0] = px; sx[i][1] = py; sx[i][2] = pz;
+        srad[i] = r; sx[i][0] = px; sx[i][1] = py; sx[i][2] = pz; ssrc[i] = src;
         elements[(size_t)b * D + i] = z;
     }
     __syncthreads();
+    if (x_out)
+        for (int i = threadIdx.x; i < N * 3; i += 256) {
+            const int a = i / 3;
+            x_out[(size_t)b * N * 3 + i] = a < n ? sx[a][i - a * 3] : 0.f;
+        }
     for (int idx = threadIdx.x; idx < D * D; idx += 256) {
         const int i = idx / D, j = idx - i * D;
         float d = 0.f, a = 0.f;
         if (i < n && j < n) {
             const float dx = sx[i][0] - sx[j][0], dy = sx[i][1] - sx[j][1], dz = sx[i][2] - sx[j][2];
             d = sqrtf(dx * dx + dy * dy + dz * dz);
-            if (i != j && d < cov_factor * (srad[i] + srad[j])) a = 1.f;
+            if (i != j) {
+                if (conn_in) a = conn_in[(size_t)b * D * D + ssrc[i] * D + ssrc[j]] ? 1.f : 0.f;
+                else if (d < cov_factor * (srad[i] + srad[j])) a = 1.f;
+            }
         }
         if (i == j) { d += 1.f; a = 1.f; }            // + I on the full 42-diagonal (mol_utils.py:175-187)
         dist[(size_t)b * D * D + idx] = d;
@@ -299,13 +318,24 @@ int mcg_gcn_forward(mcg_gcn* g, const int64_t* elements, const float* dist_mat, 
 }
 
 // elements[B,42] i64, dist_mat[B,42,42], adj_mat[B,42,42] from sampler outputs x[B,N,3], h[B,N,8] (one-hot)
-int mcg_handoff(const float* x, const float* h, const int32_t* n_nodes_dev, int B, int N, float cov_factor,
-                int64_t* elements, float* dist_mat, float* adj_mat, void* stream) {
-    if (!x || !h || !n_nodes_dev || !elements || !dist_mat || !adj_mat || B < 1 || N < 1) return MCG_ERR_ARG;
-    hipLaunchKernelGGL(k_handoff, dim3(B), dim3(256), 0, (hipStream_t)stream, x, h, n_nodes_dev, N, cov_factor, elements,
-                       dist_mat, adj_mat);
+int mcg_handoff_ex(const float* x, const float* h, const int32_t* n_nodes_dev, int B, int N, float cov_factor,
+                   const int32_t* order, const uint8_t* conn_in, int64_t* elements, float* dist_mat, float* adj_mat,
+                   float* x_out, int32_t* bad_order_flag, void* stream) {
+    if (!x || !h || !n_nodes_dev || !elements || !dist_mat || !adj_mat || B < 1 || N < 1) {
+        mcg_set_error("mcg_handoff_ex: bad arguments");
+        return MCG_ERR_ARG;
+    }
+    if (x_out == x) { mcg_set_error("mcg_handoff_ex: x_out may not alias x"); return MCG_ERR_ARG; }
+    hipLaunchKernelGGL(k_handoff, dim3(B), dim3(256), 0, (hipStream_t)stream, x, h, n_nodes_dev, N, cov_factor, order, conn_in,
+                       elements, dist_mat, adj_mat, x_out, bad_order_flag);
     MCG_HIP(hipGetLastError());
     return MCG_OK;
+}
+
+int mcg_handoff(const float* x, const float* h, const int32_t* n_nodes_dev, int B, int N, float cov_factor,
+                int64_t* elements, float* dist_mat, float* adj_mat, void* stream) {
+    return mcg_handoff_ex(x, h, n_nodes_dev, B, N, cov_factor, nullptr, nullptr, elements, dist_mat, adj_mat, nullptr, nullptr,
+                          stream);
 }
 
 // 1 if an out-of-range element id was seen since creation (nn.Embedding would have raised)

@@ -425,6 +425,11 @@ __global__ __launch_bounds__(256) void mcg_gemm_x6_kernel(McgGemmArgs p) {
 }
 
 // launch of the f32x6 variant: Bp must point to a B-pack16x3
+// Launch-shape counters (measurement / test hook, mcg_debug_gemm_launches): how many node / GCN GEMM launches were ISSUED
+// (plain or into a graph capture) per kernel family and wave-tile width since the last reset.
+// [family 0: 32-row fp32, 1: 32-row bf16, 2: 16-row-tile fp32, 3: split-operand][rn 0..7]
+extern "C" void mcg_count_gemm_launch(int family, int rn);
+
 static inline hipError_t mcg_gemm_x6_launch(const McgGemmArgs& a, hipStream_t s, int rn_override = 0) {
     if (a.M <= 0) return hipSuccess;
     const int rowblocks = (a.M + 31) / 32;
@@ -433,6 +438,7 @@ static inline hipError_t mcg_gemm_x6_launch(const McgGemmArgs& a, hipStream_t s,
     if (rn_override >= 1 && rn_override <= 3) rn = rn_override;          // mcg_egnn_set_option(MCG_OPT_GEMM_X6_RN)
     const int wave_cols = (a.n_tiles + rn - 1) / rn;
     dim3 grid((unsigned)(rowblocks * ((wave_cols + 3) / 4)));
+    mcg_count_gemm_launch(3, rn);
     if (rn == 3) hipLaunchKernelGGL(mcg_gemm_x6_kernel<3>, grid, dim3(256), 0, s, a);
     else if (rn == 2) hipLaunchKernelGGL(mcg_gemm_x6_kernel<2>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(mcg_gemm_x6_kernel<1>, grid, dim3(256), 0, s, a);
@@ -777,8 +783,13 @@ __global__ __launch_bounds__(256) void mcg_gemm16_kernel(McgGemmArgs p) {
 // ceil(side_M * 4 / 256) workgroups.
 static inline hipError_t mcg_gemm16_launch(McgGemmArgs a, int rn, hipStream_t s, int mr = 1) {
     if (a.M <= 0) return hipSuccess;
+    // the EFFECTIVE tile shape - the one an instantiation exists for - sizes the grid: a width the kernel was not built
+    // with would leave the kernel's wave_cols and the grid disagreeing (output columns silently unwritten)
+    mr = mr == 2 ? 2 : 1;
+    rn = mr == 2 ? (rn == 3 ? 3 : 2) : (rn == 6 || rn == 3 || rn == 1) ? rn : 2;
     const long waves = (long)((a.M + 16 * mr - 1) / (16 * mr)) * ((a.n_tiles + rn - 1) / rn);
     a.gemm_blocks = (int)((waves + 3) / 4);
+    mcg_count_gemm_launch(2, rn);
     const int side = a.side_x ? (a.side_M * 4 + 255) / 256 : 0;
     const dim3 grid((unsigned)(a.gemm_blocks + side));
     const int gather = (a.a2_rows != nullptr && a.K2 > 0) ? (a.a2_nsum >= 4 ? 4 : a.a2_nsum == 3 ? 3 : 2) : 0;
@@ -827,6 +838,7 @@ static inline hipError_t mcg_gemm_launch(const McgGemmArgs& a, hipStream_t s, bo
     if (rn_override >= 1 && rn_override <= 3) rn = rn_override;          // mcg_egnn_set_option(MCG_OPT_GEMM_RN)
     const long waves = (long)rowblocks * ((a.n_tiles + rn - 1) / rn);
     dim3 grid((unsigned)((waves + 3) / 4));
+    mcg_count_gemm_launch(bf16 ? 1 : 0, rn);
     if (!bf16 && a.side_x) {                 // fp32 kernel only: coordinate-update side job behind the GEMM's workgroups
         McgGemmArgs b = a;
         b.gemm_blocks = (int)grid.x;

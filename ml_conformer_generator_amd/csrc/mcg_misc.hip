@@ -4,6 +4,7 @@
 #include "mcg_common.h"
 #include "mcg_api_internal.h"
 
+#include <atomic>
 #include <cstdarg>
 #include <cstring>
 
@@ -18,7 +19,21 @@ extern "C" void mcg_set_error(const char* fmt, ...) {
 
 extern "C" const char* mcg_last_error(void) { return g_err; }
 
-extern "C" int mcg_abi_version(void) { return 2; }      // 2: mcg_plan_opts / mcg_plan_create_ex / mcg_egnn_set_option
+extern "C" int mcg_abi_version(void) { return 3; }      // 2: mcg_plan_opts / mcg_plan_create_ex / mcg_egnn_set_option; 3: mcg_handoff_ex
+
+// launch-shape counters of the GEMM launchers (mcg_gemm.h); relaxed atomics: a measurement hook, not a synchronisation point
+static std::atomic<int64_t> g_gemm_launches[4][8];
+extern "C" void mcg_count_gemm_launch(int family, int rn) {
+    if (family >= 0 && family < 4) g_gemm_launches[family][rn & 7].fetch_add(1, std::memory_order_relaxed);
+}
+extern "C" int mcg_debug_gemm_launches(int64_t* counts_host /*[32]*/, int reset) {
+    for (int f = 0; f < 4; ++f)
+        for (int r = 0; r < 8; ++r) {
+            if (counts_host) counts_host[f * 8 + r] = g_gemm_launches[f][r].load(std::memory_order_relaxed);
+            if (reset) g_gemm_launches[f][r].store(0, std::memory_order_relaxed);
+        }
+    return MCG_OK;
+}
 
 namespace {
 

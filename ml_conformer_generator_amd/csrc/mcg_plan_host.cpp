@@ -283,3 +283,26 @@ extern "C" int mcg_plan_check_tables(int B, int N, const int32_t* n_nodes_host, 
     }
     return MCG_OK;
 }
+
+std::vector<int> mcg_plan_range_cuts(int B, const int32_t* n_nodes_host, int parts) {
+    std::vector<int> cuts{0};
+    if (B < 1 || !n_nodes_host) return cuts;
+    if (parts > B) parts = B;
+    if (parts < 1) parts = 1;
+    std::vector<long> cum((size_t)B + 1, 0);
+    for (int b = 0; b < B; ++b) cum[b + 1] = cum[b] + (long)n_nodes_host[b] * (n_nodes_host[b] > 0 ? n_nodes_host[b] - 1 : 0);
+    int b0 = 0;
+    for (int k = 0; k < parts; ++k) {
+        int b1 = B;
+        if (k + 1 < parts) {
+            const long target = cum[B] * (k + 1) / parts;
+            b1 = b0 + 1;
+            while (b1 < B && cum[b1] < target) ++b1;
+            const int last = B - (parts - 1 - k);        // leave one molecule for each of the remaining ranges
+            if (b1 > last) b1 = last;
+        }
+        cuts.push_back(b1);
+        b0 = b1;
+    }
+    return cuts;
+}

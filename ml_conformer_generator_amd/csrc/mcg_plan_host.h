@@ -23,3 +23,8 @@ struct McgPlanHost {
 // `cus`: compute units of the device the plan is for (a round of the chip = 2 resident workgroups per CU).
 // `opts` may be null (defaults).  Returns MCG_OK or MCG_ERR_ARG with mcg_set_error text.
 int mcg_plan_build_host(int B, int N, const int32_t* n_nodes_host, const mcg_plan_opts* opts, int cus, McgPlanHost& H);
+
+// Cut a batch into `parts` contiguous molecule ranges of ~equal edge-row count (mcg_egnn_plan.hip runs each on its own HIP
+// stream).  Returns the range starts b0[0..parts'] with b0[0] = 0 and b0[parts'] = B; every range holds at least one
+// molecule (parts' = min(parts, B) >= 1), also when one molecule owns most of the rows.
+std::vector<int> mcg_plan_range_cuts(int B, const int32_t* n_nodes_host, int parts);

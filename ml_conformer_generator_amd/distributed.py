@@ -71,15 +71,19 @@ def draw_global_sizes(n_samples: int, min_n_nodes: int, max_n_nodes: int, group=
     return sizes.cpu()
 
 
-def gather_results(local: Dict[str, torch.Tensor], n_samples: int, group=None) -> Dict[str, torch.Tensor]:
-    """All-gather per-sample result tensors (dim 0 = sample) of unequal shard sizes.
-    Every rank returns the full batch in rank order.  Shards are padded to the largest shard
-    so that a single fixed-size all_gather per tensor suffices."""
+def gather_results(local: Dict[str, torch.Tensor], n_samples: int, group=None, dst: Optional[int] = None
+                   ) -> Dict[str, torch.Tensor]:
+    """Gather per-sample result tensors (dim 0 = sample) of unequal shard sizes - the ONE data-path collective.
+    `dst` None: all-gather, every rank returns the full batch in rank order.  `dst` = a group rank: `gather` to that rank
+    only; it returns the full batch, every other rank its OWN shard (no replicated D2H copy / record assembly on the
+    ranks that do not consume the batch).  Shards are padded to the largest shard so that one fixed-size collective per
+    tensor suffices."""
     if not dist.is_available() or not dist.is_initialized():
         return local
     world = dist.get_world_size(group)
     if world == 1 and not os.environ.get("MCG_FORCE_COLLECTIVE"):
         return local          # (MCG_FORCE_COLLECTIVE=1: run the collective on a 1-rank group - RCCL smoke check)
+    rank = dist.get_rank(group)
     sizes = shard_sizes(n_samples, world)
     cap = max(sizes)
     # gloo (CPU tests, or a multi-process dry run on one GPU) cannot move device tensors
@@ -89,9 +93,18 @@ def gather_results(local: Dict[str, torch.Tensor], n_samples: int, group=None) -
         src = t.cpu() if via_host else t
         pad = torch.zeros((cap,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
         pad[: src.shape[0]] = src
-        buf = torch.empty((world * cap,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
-        dist.all_gather_into_tensor(buf, pad.contiguous(), group=group)
-        parts = [buf[r * cap: r * cap + sizes[r]] for r in range(world)]
+        if dst is None:
+            buf = torch.empty((world * cap,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+            dist.all_gather_into_tensor(buf, pad.contiguous(), group=group)
+            parts = [buf[r * cap: r * cap + sizes[r]] for r in range(world)]
+        else:
+            recv = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+            dist.gather(pad.contiguous(), gather_list=recv, dst=dist.get_global_rank(group, dst) if group is not None else dst,
+                        group=group)
+            if rank != dst:
+                out[key] = t
+                continue
+            parts = [recv[r][: sizes[r]] for r in range(world)]
         full = torch.cat(parts, dim=0)
         out[key] = full.to(t.device) if via_host else full
     return out
@@ -129,8 +142,8 @@ def exchange_status(ok: bool, group=None) -> List[bool]:
 
 def sharded_generate(n_samples: int, draw_sizes: Callable[[], torch.Tensor],
                      run_shard: Callable[[torch.Tensor, int, int], Dict[str, torch.Tensor]], group=None,
-                     seed: Optional[int] = None, seed_fn: Optional[Callable[[int], None]] = None
-                     ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+                     seed: Optional[int] = None, seed_fn: Optional[Callable[[int], None]] = None,
+                     gather_dst: Optional[int] = None) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
     """The sharded generation step every multi-GPU entry point goes through
     (`MLConformerGenerator.generate_conformers_sharded`, `bench.py --gpus N`):
 
@@ -144,7 +157,8 @@ def sharded_generate(n_samples: int, draw_sizes: Callable[[], torch.Tensor],
       status = exchange_status(...)             # one byte per rank; ShardError on EVERY rank if any shard failed
       full   = gather_results(local)            # the ONLY data-path collective, at the very end
 
-    Returns (sizes, full) on every rank; `full` is in sample order."""
+    Returns (sizes, full) on every rank; `full` is in sample order.  `gather_dst` = a group rank: only that rank receives
+    the full batch (`gather`), the others get their own shard back."""
     world, rank = world_and_rank(group)
     sizes = draw_sizes()
     if sizes.numel() != n_samples:
@@ -172,4 +186,4 @@ def sharded_generate(n_samples: int, draw_sizes: Callable[[], torch.Tensor],
         if failure is not None:
             raise ShardError(f"{msg}; this rank ({rank}): {type(failure).__name__}: {failure}") from failure
         raise ShardError(msg + f"; this rank ({rank}) finished its shard")
-    return sizes, gather_results(local, n_samples, group)
+    return sizes, gather_results(local, n_samples, group, dst=gather_dst)

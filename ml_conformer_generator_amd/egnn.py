@@ -8,6 +8,7 @@ reference's state-dict layout and repacked by the library.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Dict, Optional
 
 import torch
@@ -54,6 +55,16 @@ class BatchPlan:
         idx = torch.arange(self.N).unsqueeze(0)
         return (idx < self.n_nodes_host.unsqueeze(1)).to(torch.float32).unsqueeze(2).to(self.device)
 
+    def edge_mask(self) -> torch.Tensor:
+        """The ONE edge mask the plan's kernels implement, [B*N*N, 1] on the device: outer product of the prefix node
+        mask with the diagonal removed (`prepare_masks`, mol_utils.py:246-249).  Built once per plan."""
+        em = getattr(self, "_edge_mask", None)
+        if em is None:
+            nm = self.node_mask().squeeze(2)
+            em = nm.unsqueeze(1) * nm.unsqueeze(2) * (1.0 - torch.eye(self.N, device=self.device)).unsqueeze(0)
+            em = self._edge_mask = em.reshape(self.B * self.N * self.N, 1)
+        return em
+
     def __del__(self):
         try:
             if self._h:
@@ -89,6 +100,7 @@ class EGNNDynamics(torch.nn.Module):
         self._h = C.c_void_p()
         self.compute_dtype = "f32"
         self._plans: Dict[tuple, BatchPlan] = {}
+        self._edge_mask_ok = None          # (weakref to the last verified edge_mask tensor, its version, its plan)
 
     # -- weights ------------------------------------------------------------------
     def load_reference_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "dynamics.egnn.") -> None:
@@ -161,6 +173,25 @@ class EGNNDynamics(torch.nn.Module):
             self._plans[key] = p
         return p
 
+    def check_edge_mask(self, plan: BatchPlan, edge_mask) -> None:
+        """The reference multiplies every message by whatever `edge_mask` the caller passes (egnn.py:477-478,51,127); the
+        HIP kernels implement exactly one - the canonical mask of the plan's prefix node mask.  Any other mask is REFUSED
+        (ValueError) instead of being silently ignored.  One device compare + sync per distinct mask tensor: the verdict is
+        cached on the tensor object + its version counter, so the reference's sampler loop (the same tensor every step)
+        pays it once."""
+        if edge_mask is None:
+            return
+        hit = self._edge_mask_ok
+        if hit is not None and hit[0]() is edge_mask and hit[1] == edge_mask._version and hit[2]() is plan:
+            return
+        if edge_mask.numel() != plan.B * plan.N * plan.N:
+            raise ValueError(f"edge_mask has {edge_mask.numel()} entries, expected B*N*N = {plan.B * plan.N * plan.N}")
+        em = edge_mask.reshape(-1, 1).to(self.device, torch.float32)
+        if not bool(torch.equal(em, plan.edge_mask())):
+            raise ValueError("edge_mask is not the canonical mask of node_mask (outer product minus the diagonal, as built "
+                             "by prepare_masks): the HIP denoiser supports prefix node masks with that edge mask only")
+        self._edge_mask_ok = (weakref.ref(edge_mask), edge_mask._version, weakref.ref(plan))
+
     # -- operator seam ------------------------------------------------------------
     def run(self, plan: BatchPlan, t: torch.Tensor, xh: torch.Tensor, context: torch.Tensor,
             out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -173,10 +204,12 @@ class EGNNDynamics(torch.nn.Module):
 
     @torch.no_grad()
     def forward(self, t, xh, node_mask, edge_mask, context):
-        """out[B,N,11] - same contract as the reference (egnn.py:472-513).  `edge_mask`
-        is accepted for interface parity; it is fully determined by `node_mask`."""
+        """out[B,N,11] - same contract as the reference (egnn.py:472-513).  `edge_mask` must be the canonical mask of
+        `node_mask` (it is fully determined by it in every caller of the reference); anything else raises ValueError
+        (`check_edge_mask`).  None skips the check."""
         B, N, _ = xh.shape
         plan = self.plan(sizes_from_node_mask(node_mask), N)
+        self.check_edge_mask(plan, edge_mask)
         f32 = dict(device=self.device, dtype=torch.float32)
         return self.run(plan, t.reshape(B).to(**f32).contiguous(), xh.to(**f32).contiguous(),
                         context.to(**f32).contiguous())

@@ -105,10 +105,11 @@ class EquivariantDiffusion(torch.nn.Module):
         dynamics).  What a run RETURNS (`x`, `h` of `_decode`, the tensor of `sample_combined_position_feature_noise`) is
         always a fresh tensor and is never overwritten by a later run; the in-place latent handed to `trace` is cloned."""
 
-        def __init__(self, model: "EquivariantDiffusion", node_mask, context):
+        def __init__(self, model: "EquivariantDiffusion", node_mask, context, edge_mask=None):
             dev = model.device
             self.B, self.N = int(node_mask.shape[0]), int(node_mask.shape[1])
             self.plan: BatchPlan = model.dynamics.plan(sizes_from_node_mask(node_mask), self.N)
+            model.dynamics.check_edge_mask(self.plan, edge_mask)      # a non-canonical edge mask is refused, not ignored
             # Latent, network output and context live in buffers owned by the (cached) plan: the denoiser call is a HIP
             # graph keyed by these addresses, so a second sampling run over the same batch shape replays the captured
             # graph instead of re-capturing it (or, from the third run on, paying three staging copies per call).
@@ -183,7 +184,7 @@ class EquivariantDiffusion(torch.nn.Module):
     @torch.no_grad()
     def forward(self, node_mask, edge_mask, context, resample_steps: int = 0):
         """Draw samples (:365-421): T*(1+resample_steps) network calls + 1 decode call."""
-        run = self._Run(self, node_mask, context)
+        run = self._Run(self, node_mask, context, edge_mask)
         z = self._noise(run, out=run.z_buf)
         for s_int in range(self.T - 1, -1, -1):
             for _ in range(resample_steps + 1):
@@ -195,7 +196,7 @@ class EquivariantDiffusion(torch.nn.Module):
                 blend_power: int = 3):
         """Sampling with a fixed fragment blended back in every step (:423-513)."""
         resample_steps = max(1, resample_steps)
-        run = self._Run(self, node_mask, context)
+        run = self._Run(self, node_mask, context, edge_mask)
         zk = z_known.to(self.device, torch.float32).contiguous()
         fm = fixed_mask.to(self.device, torch.float32).contiguous()
         z = self._noise(run, out=run.z_buf)
@@ -214,7 +215,7 @@ class EquivariantDiffusion(torch.nn.Module):
         resample_steps = max(1, resample_steps)
         if diffusion_level > self.T or diffusion_level < 0:
             raise IndexError(f"index {diffusion_level} is out of bounds for dimension 0 with size {self.T + 1}")
-        run = self._Run(self, node_mask, context)
+        run = self._Run(self, node_mask, context, edge_mask)
         zk = z_known.to(self.device, torch.float32).contiguous()
         fm = fixed_mask.to(self.device, torch.float32).contiguous()
         z = self._blend(run, run.z_buf, zk, None, diffusion_level, blend_power, 0)

@@ -85,39 +85,57 @@ _BOND_VALENCE2 = (0, 2, 4, 6, 3)          # twice the valence of bond classes no
 
 
 def adj_mat_seer_input(positions: torch.Tensor, one_hot: torch.Tensor, n_nodes: torch.Tensor, dimension: int = 42,
-                       cov_factor: float = 1.3):
+                       cov_factor: float = 1.3, order=None, conn=None, return_coords: bool = False):
     """Tensor half of `samples_to_rdkit_mol` (mol_utils.py:18-57) + `prepare_adj_mat_seer_input` (:146-194),
     one molecule at a time like the reference:
       * atoms = argmax(one_hot) -> element symbol (:41-45); the coordinates travel through the XYZ text block
         written with "%.9f" (:46-51) and come back as DOUBLES (`torch.tensor(conf.GetPositions())`, :171);
+      * [`canonicalise`, :110-126] `RenumberAtoms(mol, order)`: the atom at position p of everything below is
+        generation atom order[b][p];
       * elements = atomic numbers, zero padded (`MolGraph.elements_vector`, molgraph.py:224-234);
       * dist_mat = fp64 `distance_matrix` (:129-143), zero padded to `dimension`, + I, stored into the fp32
         batch tensor (:178-187);
       * adj_mat = (1-order connectivity > 0) + I clamped to {0, 1} (:175-180).
-    SUBSTITUTES (parity unpinned, RDKit absent): the connectivity is the covalent-radius rule
-    d_ij < cov_factor * (r_i + r_j) that RDKit's `DetermineConnectivity` documents (instead of the RDKit call,
-    :117), and atoms keep their generation order (instead of the canonical SMILES order, :118-124)."""
+    The two RDKit-owned decisions are ARGUMENTS: `order` (list of per-molecule permutations, the value of
+    `_smilesAtomOutputOrder`, :118-124) and `conn` (list of per-molecule {0,1} [n,n] connectivities in GENERATION order,
+    what `DetermineConnectivity` perceives before the renumbering, :117).  Left None they take the SUBSTITUTES (parity
+    unpinned, RDKit absent): the covalent-radius rule d_ij < cov_factor * (r_i + r_j) that RDKit's
+    `DetermineConnectivity` documents, and generation order.
+    `return_coords`: also the fp64 coordinates in the order of the GCN input (the `canonicalised_samples`)."""
     B = positions.size(0)
     elements = torch.zeros(B, dimension, dtype=torch.long)
     dist_b = torch.zeros(B, dimension, dimension)
     adj_b = torch.zeros(B, dimension, dimension)
+    coords_out = []
     for b in range(B):
         n = int(n_nodes[b])
+        perm = list(range(n)) if order is None or order[b] is None else [int(v) for v in order[b]][:n]
+        assert sorted(perm) == list(range(n)), "order must be a permutation of the molecule's atoms"
         atoms = torch.argmax(one_hot[b], dim=1)
-        z = [_ATOMIC_NUMBER[_ATOM_DECODER[int(atoms[i])]] for i in range(n)]
-        coord = torch.tensor([[float("%.9f" % float(positions[b, i, k])) for k in range(3)] for i in range(n)],
-                             dtype=torch.float64).reshape(n, 3)
+        z_gen = [_ATOMIC_NUMBER[_ATOM_DECODER[int(atoms[i])]] for i in range(n)]
+        coord_gen = torch.tensor([[float("%.9f" % float(positions[b, i, k])) for k in range(3)] for i in range(n)],
+                                 dtype=torch.float64).reshape(n, 3)
+        if conn is None or conn[b] is None:
+            r = torch.tensor([_RCOV[v] for v in z_gen], dtype=torch.float64)
+            conn_gen = (pairwise_distance(coord_gen) < cov_factor * (r.unsqueeze(0) + r.unsqueeze(1)))
+        else:
+            conn_gen = torch.as_tensor(conn[b])[:n, :n] != 0
+        conn_gen = conn_gen & ~torch.eye(n, dtype=torch.bool)
+        idx = torch.tensor(perm, dtype=torch.long)
+        z = [z_gen[i] for i in perm]                                   # RenumberAtoms: new atom p = old atom order[p]
+        coord = coord_gen[idx].reshape(n, 3)
         dist = pairwise_distance(coord)
         pad = torch.nn.functional.pad(dist, (0, dimension - n, 0, dimension - n), "constant", 0) + torch.eye(dimension)
-        r = torch.tensor([_RCOV[v] for v in z], dtype=torch.float64)
-        conn = (dist < cov_factor * (r.unsqueeze(0) + r.unsqueeze(1))) & ~torch.eye(n, dtype=torch.bool)
         sc = torch.zeros(dimension, dimension)
-        sc[:n, :n] = conn.float()
+        sc[:n, :n] = conn_gen[idx][:, idx].float()
         sc = sc + torch.eye(dimension)
         sc[sc > 0] = 1
         elements[b, :n] = torch.tensor(z, dtype=torch.long)
         dist_b[b] = pad                     # fp64 -> fp32 on assignment, as in the reference
         adj_b[b] = sc
+        coords_out.append(coord)
+    if return_coords:
+        return elements, dist_b, adj_b, coords_out
     return elements, dist_b, adj_b
 
 

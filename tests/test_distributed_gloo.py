@@ -77,7 +77,8 @@ def _shell_generator():
     gen.device = torch.device("cpu")
     gen.dimension = 42
     gen.min_n_nodes, gen.max_n_nodes = 15, 39
-    gen.last_batch = gen.last_valid_fraction = gen._timing = gen.last_noise_seed = None
+    gen.last_batch = gen.last_valid_fraction = gen._timing = gen.last_noise_seed = gen.last_host_assembly_ms = None
+    gen.atom_order_provider = None
     return gen
 
 
@@ -132,6 +133,48 @@ def test_generate_conformers_sharded_world2_gloo():
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, 11, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
+def _rank0_gather_worker(rank, world, port, n_samples, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(1000 + 17 * rank)
+    gen = _shell_generator()
+    gen._generate_shard = _stub_shard([])
+    mols = gen.generate_conformers_sharded(reference_context=torch.tensor([50.0, 100.0, 130.0]), n_atoms=27, variance=12,
+                                           n_samples=n_samples, gather="rank0")
+    torch.manual_seed(1000)
+    expect = torch.randint(15, 40, (n_samples,))
+    lo, hi = shard_range(n_samples, rank, world)
+    mine = expect if rank == 0 else expect[lo:hi]          # rank 0: the whole batch; the others: their own shard only
+    ok = [m.GetNumAtoms() for m in mols] == [int(v) for v in mine.tolist() if v % 2 == 0]
+    ok = ok and gen.last_host_assembly_ms is not None and gen.last_host_assembly_ms < 1000.0
+    try:
+        gen.generate_conformers_sharded(reference_context=torch.tensor([50.0, 100.0, 130.0]), n_atoms=27, n_samples=2,
+                                        gather="everyone")
+        ok = False
+    except ValueError:
+        pass
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_to_rank0_only_world2_gloo():
+    """Multi-GPU readiness: with `gather="rank0"` the final collective is a `gather` - rank 0 returns the whole batch in
+    sample order, every other rank only its own shard (no replicated D2H copy + record assembly on ranks that do not
+    consume the batch)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank0_gather_worker, args=(r, 2, port, 11, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=180) for _ in procs)

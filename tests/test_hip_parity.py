@@ -274,10 +274,42 @@ def test_model_options_and_measurement_hooks(edm_sd):
     ref = EO.egnn_dynamics(edm_sd, t, z, nm, em, ctx)
     d = EGNNDynamics(device=DEV)
     d.load_reference_state_dict(edm_sd)
-    for rn in (1, 2, 3, 0):
-        d.set_option(_lib.OPT_GEMM_RN, rn)
-        ok, err, sc = close(d(t.to(DEV), z.to(DEV), nm.to(DEV), em.to(DEV), ctx.to(DEV)), ref)
-        assert ok, (rn, err, sc)
+    L = _lib.lib()
+
+    def launches(reset=True):
+        c = np.zeros(32, dtype=np.int64)
+        _lib.check(L.mcg_debug_gemm_launches(c.ctypes.data, 1 if reset else 0), "mcg_debug_gemm_launches")
+        return c.reshape(4, 8)
+
+    # fp32 at 114 atoms: every node GEMM takes the 16-row-tile kernel, which MCG_OPT_GEMM_RN does not steer (round-3
+    # advisor: the old loop over this option in fp32 mode tested nothing) - said here, with the launch counters
+    launches()
+    ok, err, sc = close(d(t.to(DEV), z.to(DEV), nm.to(DEV), em.to(DEV), ctx.to(DEV)), ref)
+    c = launches()
+    assert ok and int(c[2].sum()) == 63 and int(c[0].sum()) == 0, (err, sc, c)
+    # bf16 mode: the 32-row kernel runs all 63 GEMMs and the option picks its wave tile width.  The option is set through
+    # the C ABI AFTER the plan captured its graph, without dropping the plan: the option epoch in the graph key must
+    # force a re-capture (round-3 advisor), and the counters must show the new width.
+    d.set_precision("bf16")
+    pl = d.plan(sizes, N)
+    zt0, ct0, tt0 = z.to(DEV), ctx.to(DEV), t.reshape(-1).to(DEV).contiguous()
+    outs = {}
+    for rn in (0, 1, 2, 3):
+        _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_GEMM_RN, rn), "mcg_egnn_set_option")      # plan and graph stay
+        launches()
+        outs[rn] = d.run(pl, tt0, zt0, ct0).clone()
+        c = launches()
+        assert int(c[1].sum()) == 63, (rn, c)                      # re-captured: 63 launches issued again
+        if rn:
+            assert int(c[1][rn]) == 63, (rn, c)                    # ... all of them at the requested width
+        launches()
+        d.run(pl, tt0, zt0, ct0)
+        assert int(launches().sum()) == 0                          # unchanged options: the graph is replayed
+        assert float((outs[rn] - ref.to(DEV)).abs().max()) <= 3e-2 * float(ref.abs().max())
+    for rn in (1, 2, 3):                                           # same k order per output element at every width
+        assert torch.equal(outs[rn], outs[1])
+    _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_GEMM_RN, 0), "mcg_egnn_set_option")
+    d.set_precision("f32")
     with pytest.raises(_lib.McgError):
         d.set_option(_lib.OPT_GEMM_RN, 7)
     with pytest.raises(_lib.McgError):
@@ -360,6 +392,35 @@ def test_non_prefix_mask_rejected(dyn):
     nm[0, 1:4] = 1
     with pytest.raises(ValueError):
         dyn(torch.zeros(1, 1), torch.zeros(1, 5, 11), nm, torch.zeros(25, 1), torch.zeros(1, 5, 3))
+
+
+def test_non_canonical_edge_mask_is_refused_not_ignored(dyn, sampler_factory):
+    """The reference multiplies by whatever `edge_mask` it is given (egnn.py:477-478,51,127); the HIP path implements the
+    canonical mask of the prefix node mask only, so any other mask must raise - through op seam 1 and through the sampler
+    entry points - and the canonical mask (any shape with B*N*N entries), or None, must pass.  The verdict is cached per
+    tensor object + version: an in-place edit of an accepted mask is noticed."""
+    g = load_golden("dynamics_b4n19.npz")
+    nm, xh, ctx, t = g["node_mask"], g["xh"], g["context"], g["t"]
+    em = edge_mask_of(nm)
+    ref = dyn(t.to(DEV), xh.to(DEV), nm.to(DEV), em.to(DEV), ctx.to(DEV))
+    assert torch.equal(ref, dyn(t.to(DEV), xh.to(DEV), nm.to(DEV), None, ctx.to(DEV)))
+    assert torch.equal(ref, dyn(t.to(DEV), xh.to(DEV), nm.to(DEV), em.reshape(nm.shape[0], -1).to(DEV), ctx.to(DEV)))
+    bad = em.clone()
+    bad[int(torch.nonzero(bad)[5, 0])] = 0.0                                  # one extra zero
+    with pytest.raises(ValueError, match="canonical"):
+        dyn(t.to(DEV), xh.to(DEV), nm.to(DEV), bad.to(DEV), ctx.to(DEV))
+    with pytest.raises(ValueError, match="entries"):
+        dyn(t.to(DEV), xh.to(DEV), nm.to(DEV), em[:-1].to(DEV), ctx.to(DEV))
+    live = em.to(DEV)
+    dyn(t.to(DEV), xh.to(DEV), nm.to(DEV), live, ctx.to(DEV))                  # accepted and cached ...
+    live[int(torch.nonzero(live)[0, 0])] = 0.0                                 # ... then edited in place
+    with pytest.raises(ValueError, match="canonical"):
+        dyn(t.to(DEV), xh.to(DEV), nm.to(DEV), live, ctx.to(DEV))
+    gm = sampler_factory(4)
+    with pytest.raises(ValueError, match="canonical"):
+        gm(nm.to(DEV), bad.to(DEV), ctx.to(DEV), 0)
+    x, h = gm(nm.to(DEV), em.to(DEV), ctx.to(DEV), 0)
+    assert bool(torch.isfinite(x).all())
 
 
 # (mode "f32x6": the opt-in split-operand kernels under the SAME per-step tolerance as the exact path - every golden
@@ -877,6 +938,167 @@ def test_handoff_kernel_vs_oracle():
     assert torch.equal(am1.cpu()[~borderline], am0[~borderline])
     assert int(borderline.sum()) < 4
     assert int(am0.sum()) > B * 42                                   # some bonds were actually perceived
+
+
+def test_handoff_ex_random_orders_and_connectivities_vs_oracle(gcn, gcn_sd):
+    """f1: `mcg_handoff_ex` with an externally supplied atom order and connectivity (the two RDKit-owned decisions of
+    `canonicalise`, mol_utils.py:110-126) against `host_oracle.adj_mat_seer_input(order=, conn=)`: random permutations
+    and random symmetric connectivities on ragged molecules (incl. n = 1, 42).  Elements and adjacency EXACT, distances to
+    fp32 rounding of the fp64 result (rtol 1e-6), permuted coordinates exact, GCN logits within 1e-4 of max|logits| of the
+    oracle GCN, bond argmax equal wherever the oracle's top-2 margin exceeds 100x the logit error."""
+    from ml_conformer_generator_amd import _lib
+    from ml_conformer_generator_amd.handoff import prepare_adj_mat_seer_input_hip
+    from oracle import gcn_oracle as GO
+    from oracle import host_oracle as HO
+    g = torch.Generator().manual_seed(41)
+    B, N = 12, 42
+    n_nodes = torch.randint(15, 40, (B,), generator=g)
+    n_nodes[0], n_nodes[1], n_nodes[2] = 42, 1, 2
+    real = (torch.arange(N).unsqueeze(0) < n_nodes.unsqueeze(1)).float().unsqueeze(2)
+    x = torch.cumsum(torch.nn.functional.normalize(torch.randn(B, N, 3, generator=g), dim=2) * 1.45, dim=1) * real
+    h = torch.nn.functional.one_hot(torch.randint(0, 8, (B, N), generator=g), 8).float() * real
+    order, conn = [], []
+    for b in range(B):
+        n = int(n_nodes[b])
+        order.append(torch.randperm(n, generator=g).tolist())
+        c = torch.rand(n, n, generator=g) < 0.12
+        c = (c | c.t()) & ~torch.eye(n, dtype=torch.bool)
+        conn.append(c.to(torch.uint8).numpy())
+    order[3] = None                                                 # a None row keeps generation order
+    for use_order, use_conn in ((True, True), (True, False), (False, True)):
+        o, c = (order if use_order else None), (conn if use_conn else None)
+        el0, dm0, am0, xc0 = HO.adj_mat_seer_input(x, h, n_nodes, order=o, conn=c, return_coords=True)
+        el1, dm1, am1, xo = prepare_adj_mat_seer_input_hip(x.to(DEV), h.to(DEV), n_nodes, order=o, connectivity=c,
+                                                           with_coords=True)
+        assert torch.equal(el1.cpu(), el0)
+        assert torch.allclose(dm1.cpu(), dm0, rtol=1e-6, atol=1e-6)
+        if use_conn:
+            assert torch.equal(am1.cpu(), am0)
+        else:
+            rc = torch.zeros(36)
+            for z, r in HO._RCOV.items():
+                rc[z] = r
+            thr = 1.3 * (rc[el0].unsqueeze(1) + rc[el0].unsqueeze(2))
+            borderline = ((dm0 - thr).abs() < 1e-5) & (thr > 0)
+            assert torch.equal(am1.cpu()[~borderline], am0[~borderline])
+        for b in range(B):
+            n = int(n_nodes[b])
+            perm = list(range(n)) if (o is None or o[b] is None) else o[b]
+            assert torch.equal(xo.cpu()[b, :n], x[b, perm]) and float(xo.cpu()[b, n:].abs().sum()) == 0.0
+        if use_order and use_conn:
+            bond, logits = gcn.bond_orders(el1, dm1, am1, with_logits=True)
+            lo = GO.adj_mat_seer(gcn_sd, el0, dm0, am0)
+            err, sc = float((logits.cpu() - lo).abs().max()), float(lo.abs().max())
+            assert err <= 1e-4 * sc, (err, sc)
+            top2 = torch.topk(lo, 2, dim=-1).values
+            safe = (top2[..., 0] - top2[..., 1]) > 100.0 * err
+            assert torch.equal(bond.cpu().to(torch.int64)[safe], lo.argmax(-1)[safe]) and float(safe.float().mean()) > 0.99
+    # malformed orders are refused on the host, before any launch
+    with pytest.raises(ValueError, match="permutation"):
+        prepare_adj_mat_seer_input_hip(x.to(DEV), h.to(DEV), n_nodes, order=[[0] * 42] * B)
+    with pytest.raises(ValueError, match="symmetric"):
+        bad = [c.copy() for c in conn]
+        bad[4][0, 1] ^= 1
+        prepare_adj_mat_seer_input_hip(x.to(DEV), h.to(DEV), n_nodes, connectivity=bad)
+    # ... and the C ABI reports an out-of-range entry through its flag instead of reading out of bounds
+    od = torch.arange(42, dtype=torch.int32).repeat(B, 1)
+    od[5, 0] = 77
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    el = torch.empty(B, 42, dtype=torch.long, device=DEV)
+    dm = torch.empty(B, 42, 42, device=DEV)
+    am = torch.empty(B, 42, 42, device=DEV)
+    xd, hd, nd, odd = x.to(DEV), h.to(DEV), n_nodes.to(DEV, torch.int32), od.to(DEV)
+    L = _lib.lib()
+    _lib.check(L.mcg_handoff_ex(xd.data_ptr(), hd.data_ptr(), nd.data_ptr(), B, N, 1.3, odd.data_ptr(), None, el.data_ptr(),
+                                dm.data_ptr(), am.data_ptr(), None, flag.data_ptr(), _lib.current_stream_ptr(DEV)), "mcg_handoff_ex")
+    assert int(flag.item()) == 1 and bool(torch.isfinite(dm).all())
+
+
+def test_generate_path_with_injected_atom_order_vs_reference_golden(sampler_factory, gcn):
+    """f1 on the COMPOSED path: HIP sampler under the reference's tape -> `mcg_handoff_ex` with the fixture's fixed
+    non-identity atom order and injected connectivity -> `mcg_gcn_forward` -> argmax, against the REFERENCE's AdjMatSeer
+    fed the same permuted input built with the reference's own `distance_matrix` (tools/make_golden.py section 9).
+    AdjMatSeer is atom-order dependent (the fixture records how many bond entries change with the order), so this pins
+    that the product hands the GCN the atoms in the order it is given, and returns coordinates in that order."""
+    from ml_conformer_generator_amd.handoff import prepare_adj_mat_seer_input_hip
+    g = load_golden("e2e_perm_T20_b4n19.npz")
+    assert int(g["order_dependent_entries"]) > 100
+    nm = g["node_mask"]
+    gm = sampler_factory(int(g["T"]), g, "f32")
+    gm.noise_fn = TapeNoise(g["noise"], DEV)
+    x, h = gm(nm.to(DEV), edge_mask_of(nm).to(DEV), g["context"].to(DEV), 0)
+    gm.noise_fn = None
+    assert torch.equal(h.cpu().to(torch.int64), g["h"].to(torch.int64))
+    x_err = float((x.cpu() - g["x"]).abs().max())
+    n_nodes = g["n_nodes"]
+    order, conn = [r.tolist() for r in g["order"]], list(g["conn_in"].numpy())
+    el, dm, am, xo = prepare_adj_mat_seer_input_hip(x, h, n_nodes.to(DEV), order=order, connectivity=conn, with_coords=True)
+    assert torch.equal(el.cpu(), g["elements"]) and torch.equal(am.cpu(), g["adj_mat"])
+    assert float((dm.cpu() - g["dist_mat"]).abs().max()) <= 4.0 * x_err + 1e-5
+    assert float((xo.cpu() - g["x_perm"]).abs().max()) <= x_err + 1e-7
+    bond, logits = gcn.bond_orders(el, dm, am, with_logits=True)
+    l_err, l_sc = float((logits.cpu() - g["logits"]).abs().max()), float(g["logits"].abs().max())
+    assert l_err <= 1e-3 * l_sc, (l_err, l_sc)
+    D = 42
+    inside = (torch.arange(D).view(1, D, 1) < n_nodes.view(-1, 1, 1)) & (torch.arange(D).view(1, 1, D) < n_nodes.view(-1, 1, 1))
+    safe = g["margin"] > 100.0 * l_err
+    got = bond.cpu().to(torch.int64)
+    assert torch.equal(got[safe], g["argmax"][safe])
+    assert float((~safe & inside).sum()) / float(inside.sum()) < 0.01
+    print(f"e2e_perm: logit err {l_err:.2e} (scale {l_sc:.2e}); bond argmax differs from the reference on "
+          f"{int(((got != g['argmax']) & inside).sum())} in-molecule entries")
+    # the same sampler output in GENERATION order gives different bonds: the order matters and is honoured
+    el_g, dm_g, am_g = prepare_adj_mat_seer_input_hip(x, h, n_nodes.to(DEV), connectivity=conn)
+    bond_g = gcn.bond_orders(el_g, dm_g, am_g).cpu().to(torch.int64)
+    moved = 0
+    for b in range(el.shape[0]):
+        n = int(n_nodes[b])
+        inv = torch.argsort(torch.tensor(order[b][:n]))
+        moved += int((got[b][:n, :n][inv][:, inv] != bond_g[b][:n, :n]).sum())
+    assert moved > 100
+
+
+def test_generator_uses_an_injected_atom_order_provider(edm_sd, gcn_sd):
+    """`MLConformerGenerator(atom_order_provider=...)`: the provider sees every molecule in generation order (atomic
+    numbers + fp64 coordinates), its order / connectivity reach the GCN, the returned records carry atoms, coordinates and
+    bonds in the PROVIDER's order, and a molecule the provider cannot build is dropped (the reference drops a
+    `MolFromXYZBlock` failure, mol_utils.py:53-55)."""
+    import numpy as np
+    from ml_conformer_generator_amd import MLConformerGenerator
+    from ml_conformer_generator_amd.handoff import molecules_from_tensors
+    seen = []
+
+    def reversing_provider(z, coords):
+        seen.append((list(z), np.array(coords)))
+        if len(seen) == 2:
+            return None                                            # "could not be built"
+        n = len(z)
+        d = np.linalg.norm(coords[:, None, :] - coords[None, :, :], axis=2)
+        return list(range(n - 1, -1, -1)), ((d < 1.9) & ~np.eye(n, dtype=bool)).astype(np.uint8)
+
+    gen = MLConformerGenerator(diffusion_steps=4, device=DEV, edm_weights=edm_sd,
+                               adj_mat_seer_weights=gcn_sd, atom_order_provider=reversing_provider)
+    ctx = torch.tensor([53.6424, 108.3042, 151.4399])
+    torch.manual_seed(3)
+    res = gen._generate_shard(ctx, 17, 2, None, 5, 0, None, True, 3, 50)
+    lb = gen.last_batch
+    assert len(seen) == 5
+    n_nodes = lb["n_nodes"].cpu()
+    mols = molecules_from_tensors(res["x"], res["elements"], res["bond"], res["n_nodes"], res["valid"])
+    assert not mols[1].valid
+    zt = torch.tensor([6, 7, 8, 9, 15, 16, 17, 35])
+    for b in (0, 2, 3, 4):
+        n = int(n_nodes[b])
+        z_gen = zt[lb["h"][b, :n].argmax(1).cpu()].tolist()
+        assert seen[b][0] == z_gen and np.allclose(seen[b][1], lb["x"][b, :n].cpu().double().numpy())
+        assert mols[b].atomic_numbers == z_gen[::-1]
+        assert torch.equal(mols[b].coords, lb["x"][b, :n].cpu().flip(0))
+    # generation order + covalent rule when there is no provider (no RDKit here): the documented substitutes
+    gen2 = MLConformerGenerator(diffusion_steps=4, device=DEV, edm_weights=edm_sd, adj_mat_seer_weights=gcn_sd)
+    assert gen2.atom_order_provider is None
+    torch.manual_seed(3)
+    res2 = gen2._generate_shard(ctx, 17, 2, None, 5, 0, None, True, 3, 50)
+    assert torch.equal(res2["x"], gen2.last_batch["x"])
 
 
 def test_bond_writeback_kernel_vs_oracle():
@@ -1457,3 +1679,25 @@ def test_bench_workload_stays_finite_over_100_steps(gcn_sd, n_samples, variance)
         torch.cuda.manual_seed(7)
         bad._generate_shard(ctx, 27, 0, None, 64, 0, None, True, 3, 50)
         assert not bool(torch.isfinite(bad.last_batch["x"]).all())
+
+
+def test_sharded_path_on_one_rank_rccl_in_a_fresh_process():
+    """Multi-GPU readiness (no 8-GPU box is available to the build): the RCCL code path of the sharded product entry point
+    on HARDWARE.  A fresh child process (never a re-exec of one that touched the GPU) initialises a 1-rank `nccl` group
+    with `device_id`, forces the collectives (MCG_FORCE_COLLECTIVE=1: status byte + result all-gather / gather on device
+    tensors) and checks `generate_conformers_sharded` against the unsharded call under the same seeds - bit-identical
+    tensors.  tools/rccl_one_rank_check.py prints one JSON line."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29573", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "rccl_one_rank_check.py")], capture_output=True,
+                       text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    print(line)
+    assert line["backend"] == "nccl" and line["world"] == 1 and line["identical_to_unsharded"] and line["finite"]
+    assert len(line["sizes"]) == 8 and 17 <= min(line["sizes"]) and max(line["sizes"]) <= 23

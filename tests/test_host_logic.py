@@ -301,6 +301,7 @@ def test_plan_builder_under_address_and_ub_sanitizers(tmp_path):
     lines.append(" ".join(map(str, [2, 256, 4, 0, 0] + [2] * 33)))                    # refused: > 16 atoms per 64-row unit
     lines.append(" ".join(map(str, [5, 256, 1, 0, 0] + [6, 3])))                      # refused: n_nodes > N
     lines.append(" ".join(map(str, [60, 256, 1, 0, 1] + [60, 55, 47])))               # no unit tables (N > ~50): row table only
+    lines.append(" ".join(map(str, [60, 256, 1, 0, 1] + [10] * 7 + [60])))            # advisor r3: the last molecule owns most rows
     f = tmp_path / "batches.txt"
     f.write_text("\n".join(lines) + "\n")
     r = subprocess.run([exe, str(f)], capture_output=True, text=True, timeout=600,
@@ -346,3 +347,137 @@ def test_finish_without_rdkit_filters_by_proxy_and_warns_once():
     assert sum("optimise_geometry" in str(x.message) for x in w) == 1          # once per process
     assert CG._finish([], True) == ([], 0.0)
     assert "V2000" in mols[0].to_molblock() and "M  END" in mols[0].to_molblock()
+
+
+def test_lazy_molecule_records_assemble_in_constant_python_work_per_molecule():
+    """Multi-GPU readiness: every rank of a sharded call assembles the records of the WHOLE gathered batch; that used to
+    cost 36-97 us per molecule (slicing + two clones) = 70-170 ms at 8 x 256.  Lazy views: 2 048 molecules in <= 25 ms
+    (best of 3: the bound is on the work, not on a GC pause), and the views read the right slices."""
+    import time
+    from ml_conformer_generator_amd.handoff import molecules_from_tensors
+    g = torch.Generator().manual_seed(5)
+    B = 2048
+    x = torch.randn(B, 39, 3, generator=g)
+    el = torch.randint(6, 10, (B, 42), generator=g).to(torch.int8)
+    bd = torch.randint(0, 5, (B, 42, 42), generator=g).to(torch.int8)
+    n = torch.randint(15, 40, (B,), generator=g).to(torch.int32)
+    v = (torch.rand(B, generator=g) < 0.5).to(torch.uint8)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        mols = molecules_from_tensors(x, el, bd, n, v)
+        best = min(best, time.perf_counter() - t0)
+    assert best <= 0.025, f"{best * 1e3:.1f} ms for {B} molecules"
+    assert len(mols) == B
+    for b in (0, 7, 2047):
+        k = int(n[b])
+        m = mols[b]
+        assert m.GetNumAtoms() == k and m.valid == bool(v[b])
+        assert m.atomic_numbers == el[b, :k].tolist() and torch.equal(m.coords, x[b, :k])
+        assert torch.equal(m.bond_orders, bd[b, :k, :k]) and len(m.symbols) == k
+    mols[3].valid = False                      # records stay independent of each other
+    assert mols[4].valid == bool(v[4])
+
+
+def test_atom_order_provider_plumbing_with_a_fake_provider():
+    """`rdkit_order.batch_order_and_connectivity` + the host-side validation of `handoff.py`, driven by fake providers
+    (RDKit is absent here; the real `rdkit_provider` follows the reference's call sequence and is labelled untested)."""
+    import numpy as np
+    from ml_conformer_generator_amd import handoff, rdkit_order
+    torch.manual_seed(2)
+    B, N = 4, 19
+    n_nodes = torch.tensor([15, 19, 17, 16])
+    real = (torch.arange(N).unsqueeze(0) < n_nodes.unsqueeze(1)).float().unsqueeze(2)
+    x = torch.randn(B, N, 3) * real
+    h = torch.nn.functional.one_hot(torch.randint(0, 8, (B, N)), 8).float() * real
+    calls = []
+
+    def fake(z, coords):
+        calls.append((z, coords.copy()))
+        n = len(z)
+        if len(calls) == 3:
+            return None
+        return list(np.roll(np.arange(n), 1)), np.eye(n, k=1, dtype=np.uint8) + np.eye(n, k=-1, dtype=np.uint8)
+
+    order, conn, built = rdkit_order.batch_order_and_connectivity(fake, x, h, n_nodes)
+    assert built == [True, True, False, True] and order[2] is None and order[0][0] == 14
+    assert conn[2].shape == (17, 17) and int(conn[2].sum()) == 0             # placeholder for the dropped molecule
+    zt = [6, 7, 8, 9, 15, 16, 17, 35]
+    assert calls[1][0] == [zt[k] for k in h[1].argmax(1).tolist()] and calls[1][1].dtype == np.float64
+    assert np.allclose(calls[0][1], x[0, :15].double().numpy()) and calls[0][1].shape == (15, 3)
+    ot = handoff._order_tensor(order, n_nodes.tolist(), 42)
+    assert ot.dtype == torch.int32 and ot.shape == (4, 42) and ot[2].tolist() == list(range(42)) and int(ot[0, 0]) == 14
+    assert ot[0, 15:].tolist() == list(range(15, 42))
+    ct = handoff._conn_tensor(conn, n_nodes.tolist(), 42)
+    assert ct.dtype == torch.uint8 and int(ct[0, 0, 1]) == 1 and int(ct[0, 15:].sum()) == 0
+    with pytest.raises(ValueError, match="permutation"):
+        handoff._order_tensor([[0, 0, 1]], [3], 42)
+    with pytest.raises(ValueError, match="rows"):
+        handoff._order_tensor([[0, 1, 2]], [3, 3], 42)
+    with pytest.raises(ValueError, match="symmetric"):
+        handoff._conn_tensor([np.array([[0, 1], [0, 0]])], [2], 42)
+    # order only / connectivity only / nothing
+    o, c, b = rdkit_order.batch_order_and_connectivity(lambda z, xyz: (list(range(len(z)))[::-1], None), x, h, n_nodes)
+    assert c is None and o[1] == list(range(18, -1, -1)) and all(b)
+    o, c, b = rdkit_order.batch_order_and_connectivity(lambda z, xyz: (None, None), x, h, n_nodes)
+    assert o is None and c is None
+    with pytest.raises(ValueError, match="every molecule or for none"):
+        k = [0]
+
+        def half(z, xyz):
+            k[0] += 1
+            return None, (np.zeros((len(z), len(z))) if k[0] % 2 else None)
+        rdkit_order.batch_order_and_connectivity(half, x, h, n_nodes)
+    # the XYZ text and the order property parse exactly as the reference writes / reads them (mol_utils.py:39-51,119-122)
+    assert rdkit_order.xyz_block([6, 17], [[0.0, 1.0, -2.5], [1.0, 0.0, 0.0]]) == \
+        "2\n\nC 0.000000000 1.000000000 -2.500000000\nCl 1.000000000 0.000000000 0.000000000\n"
+    assert rdkit_order.parse_smiles_output_order("[3,0,1,2,]") == [3, 0, 1, 2]
+    assert rdkit_order.default_provider() is None or rdkit_order.have_rdkit()
+
+
+class _RecordingChem:
+    """Stand-in for `rdkit.Chem` that records the call sequence of `rdkit_finish.mol_from_record` (RDKit is absent)."""
+
+    class rdchem:
+        class BondType:
+            SINGLE, DOUBLE, TRIPLE, AROMATIC = "S", "D", "T", "A"
+
+    def __init__(self):
+        self.log = []
+
+    def MolFromXYZBlock(self, text):
+        self.log.append(("MolFromXYZBlock", text))
+        return {"xyz": text}
+
+    def MolToXYZBlock(self, mol):
+        self.log.append(("MolToXYZBlock",))
+        return mol["xyz"]
+
+    def EditableMol(self, mol):
+        chem = self
+
+        class Ed:
+            def AddBond(self, i, j, t):
+                chem.log.append(("AddBond", i, j, t))
+
+            def GetMol(self):
+                return "mol"
+        return Ed()
+
+
+def test_rdkit_finish_follows_the_reference_call_sequence():
+    """`redefine_bonds` (mol_utils.py:197-223) restated in `rdkit_finish.mol_from_record`: XYZ text with "%.9f" ->
+    Mol -> MolToXYZBlock -> Mol -> EditableMol.AddBond(i, j, bond_type_dict[t]) over the strict lower triangle in (i, j)
+    loop order - NOT a mol block (advisor finding of round 3).  Checked against a recording stand-in for `rdkit.Chem`."""
+    from ml_conformer_generator_amd import rdkit_finish
+    from ml_conformer_generator_amd.handoff import GeneratedMolecule
+    bo = torch.tensor([[0, 2, 0, 4], [2, 0, 1, 0], [0, 1, 0, 3], [4, 0, 3, 0]], dtype=torch.int8)
+    rec = GeneratedMolecule([8, 6, 17, 7], torch.tensor([[0.0, 0, 0], [1.2, 0, 0], [2.1, 1.4, 0], [0.123456789, -1, 2]]), bo)
+    chem = _RecordingChem()
+    assert rdkit_finish.mol_from_record(rec, Chem=chem) == "mol"
+    names = [c[0] for c in chem.log]
+    assert names == ["MolFromXYZBlock", "MolToXYZBlock", "MolFromXYZBlock", "AddBond", "AddBond", "AddBond", "AddBond"]
+    assert chem.log[0][1] == rec.to_xyz_block() and "N 0.123456791 -1.000000000 2.000000000" in chem.log[0][1]
+    assert chem.log[3:] == [("AddBond", 1, 0, "D"), ("AddBond", 2, 1, "S"), ("AddBond", 3, 0, "A"), ("AddBond", 3, 2, "T")]
+    chem2 = _RecordingChem()
+    assert rdkit_finish.mol_without_bonds(rec, Chem=chem2) == {"xyz": rec.to_xyz_block()} and len(chem2.log) == 1

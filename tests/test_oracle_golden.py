@@ -154,6 +154,39 @@ def test_composed_path_oracle_vs_reference(name, gcn_sd):
     assert int((am.sum((1, 2)) - 42).min()) > 0                     # every molecule has perceived bonds: a non-trivial GCN input
 
 
+def test_handoff_distance_half_vs_reference_distance_matrix():
+    """`host_oracle.adj_mat_seer_input` against the tensor half built with the REFERENCE's own `distance_matrix`
+    (mol_utils.py:129-143; fixture `handoff_tensor_half.npz`, generation order, covalent-radius rule): bit-exact."""
+    g = load_golden("handoff_tensor_half.npz")
+    el, dm, am = HO.adj_mat_seer_input(g["x"], g["h"], g["n_nodes"])
+    assert torch.equal(el, g["elements"]) and torch.equal(dm, g["dist_mat"]) and torch.equal(am, g["adj_mat"])
+    el, dm, am = HO.adj_mat_seer_input(g["x"], g["h"], g["n_nodes"], conn=list(g["conn_cov"]))
+    assert torch.equal(am, g["adj_mat"])
+
+
+def test_handoff_with_injected_order_and_connectivity_vs_reference(gcn_sd):
+    """The two RDKit-owned decisions injected (`canonicalise`, mol_utils.py:110-126): a fixed non-identity atom order and
+    an external connectivity, applied by the fixture generator the way the reference applies RDKit's, distances through
+    the reference's `distance_matrix`, logits from the REFERENCE's AdjMatSeer.  The oracle's hand-off is bit-exact on the
+    inputs; the oracle GCN reproduces the reference's bonds on the permuted input; and the fixture itself records that the
+    GCN is order dependent (hundreds of bond entries change with the atom order)."""
+    g = load_golden("e2e_perm_T20_b4n19.npz")
+    assert int(g["order_dependent_entries"]) > 100
+    order, conn = [r.tolist() for r in g["order"]], list(g["conn_in"])
+    el, dm, am, coords = HO.adj_mat_seer_input(g["x"], g["h"], g["n_nodes"], order=order, conn=conn, return_coords=True)
+    assert torch.equal(el, g["elements"]) and torch.equal(dm, g["dist_mat"]) and torch.equal(am, g["adj_mat"])
+    for b, c in enumerate(coords):
+        assert torch.allclose(c.float(), g["x_perm"][b, : c.shape[0]], rtol=0, atol=1e-6)
+    logits = GO.adj_mat_seer(gcn_sd, el, dm, am)
+    err = float((logits - g["logits"]).abs().max())
+    assert err <= 1e-4 * float(g["logits"].abs().max())
+    safe = g["margin"] > 100 * max(err, 1e-9)
+    assert torch.equal(logits.argmax(-1)[safe], g["argmax"][safe]) and float(safe.float().mean()) > 0.99
+    # generation order on the same connectivity gives DIFFERENT elements rows (the permutation is not the identity)
+    el0, _, _ = HO.adj_mat_seer_input(g["x"], g["h"], g["n_nodes"], conn=conn)
+    assert not torch.equal(el0, el)
+
+
 def test_shape_tanimoto_oracle_matches_reference():
     import numpy as np
     from oracle import shape_oracle as SO

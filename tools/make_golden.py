@@ -354,6 +354,95 @@ def main():
         print(name, "bonds perceived per molecule:", (am.sum((1, 2)) - D).tolist(), " min margin inside molecules:",
               float(margin[inside].min()), " max|x|:", float(r["x"].abs().max()))
 
+    # 9. the hand-off with the two RDKit-owned decisions INJECTED (`canonicalise`, mol_utils.py:110-126, and
+    #    the MolGraph adjacency of `prepare_adj_mat_seer_input`, :146-194): RDKit is absent, so the atom order and the
+    #    1-order connectivity are fixed seeded inputs here, applied the way the reference applies RDKit's
+    #    (`RenumberAtoms(mol, order)`: new atom p = old atom order[p]; connectivity perceived BEFORE the renumbering), the
+    #    distance half through the REFERENCE's own `distance_matrix` (:129-143), then the REFERENCE's AdjMatSeer.forward.
+    #    AdjMatSeer is not permutation-equivariant (nodes_coord_fc, adj_mat_seer.py:135-138): these fixtures pin that the
+    #    product feeds it the atoms in the order it is given.
+    from ml_conformer_generator_amd.config import ATOMIC_NUMBERS
+    rcov = {6: 0.76, 7: 0.71, 8: 0.66, 9: 0.57, 15: 1.07, 16: 1.05, 17: 1.02, 35: 1.20}
+
+    def tensor_half(x, h, n_nodes, order, conn, D=42):
+        B = x.size(0)
+        el_b = torch.zeros(B, D, dtype=torch.long)
+        dm_b, am_b = torch.zeros(B, D, D), torch.zeros(B, D, D)
+        for b in range(B):
+            n = int(n_nodes[b])
+            cls_b = torch.argmax(h[b], dim=1)
+            z_gen = [ATOMIC_NUMBERS[int(cls_b[i])] for i in range(n)]
+            coord = torch.tensor([[float("%.9f" % float(x[b, i, k])) for k in range(3)] for i in range(n)],
+                                 dtype=torch.float64)
+            perm = torch.as_tensor(order[b][:n], dtype=torch.long)
+            coord_p = coord[perm]
+            dist = mu.distance_matrix(coord_p)                                   # the reference's function
+            pad = torch.nn.functional.pad(dist, (0, D - n, 0, D - n), "constant", 0) + torch.eye(D)
+            sc = torch.zeros(D, D)
+            sc[:n, :n] = torch.as_tensor(conn[b][:n, :n]).float()[perm][:, perm]
+            sc = sc + torch.eye(D)
+            sc[sc > 0] = 1
+            el_b[b, :n] = torch.tensor([z_gen[int(i)] for i in perm])
+            dm_b[b] = pad
+            am_b[b] = sc
+        return el_b, dm_b, am_b
+
+    def cov_rule(x, h, n_nodes, D=42):
+        conn = np.zeros((x.size(0), D, D), dtype=np.uint8)
+        for b in range(x.size(0)):
+            n = int(n_nodes[b])
+            cls_b = torch.argmax(h[b], dim=1)
+            r = torch.tensor([rcov[ATOMIC_NUMBERS[int(cls_b[i])]] for i in range(n)], dtype=torch.float64)
+            coord = torch.tensor([[float("%.9f" % float(x[b, i, k])) for k in range(3)] for i in range(n)],
+                                 dtype=torch.float64)
+            c = (mu.distance_matrix(coord) < 1.3 * (r.unsqueeze(0) + r.unsqueeze(1))) & ~torch.eye(n, dtype=torch.bool)
+            conn[b, :n, :n] = c.numpy()
+        return conn
+
+    r = e2e_runs["e2e_T20_b4n19.npz"]
+    n_nodes = r["node_mask"].sum(1).reshape(-1).to(torch.long)
+    B9, D9 = r["x"].size(0), 42
+    ident = np.tile(np.arange(D9, dtype=np.int32), (B9, 1))
+    conn_cov = cov_rule(r["x"], r["h"], n_nodes)
+    el, dm, am = tensor_half(r["x"], r["h"], n_nodes, ident, conn_cov)
+    save("handoff_tensor_half.npz", x=r["x"], h=r["h"], n_nodes=n_nodes, conn_cov=conn_cov, elements=el, dist_mat=dm,
+         adj_mat=am)
+    g9 = torch.Generator().manual_seed(909)
+    order = ident.copy()
+    conn_inj = conn_cov.copy()
+    for b in range(B9):
+        n = int(n_nodes[b])
+        order[b, :n] = torch.randperm(n, generator=g9).numpy()
+        flips = torch.randint(0, n, (6, 2), generator=g9)                         # an "external" perception: 6 toggled pairs
+        for i, j in flips.tolist():
+            if i != j:
+                conn_inj[b, i, j] ^= 1
+                conn_inj[b, j, i] = conn_inj[b, i, j]
+    assert any((order[b, :int(n_nodes[b])] != np.arange(int(n_nodes[b]))).any() for b in range(B9))
+    el, dm, am = tensor_half(r["x"], r["h"], n_nodes, order, conn_inj)
+    with torch.no_grad():
+        logits = gcn(el, dm, am)
+        el0, dm0, am0 = tensor_half(r["x"], r["h"], n_nodes, ident, conn_inj)
+        logits_gen_order = gcn(el0, dm0, am0)
+    top2 = torch.topk(logits, 2, dim=-1).values
+    margin = top2[..., 0] - top2[..., 1]
+    # how far the GCN is from permutation equivariance on this input: un-permute the permuted run's argmax and compare
+    am_p, am_g = torch.argmax(logits, -1), torch.argmax(logits_gen_order, -1)
+    moved = 0
+    for b in range(B9):
+        n = int(n_nodes[b])
+        inv = np.argsort(order[b, :n])
+        back = am_p[b][:n, :n][inv][:, inv]
+        moved += int((back != am_g[b][:n, :n]).sum())
+    print("e2e_perm: bond entries that differ between canonical-order and generation-order GCN input:", moved)
+    coords_perm = torch.zeros_like(r["x"])
+    for b in range(B9):
+        n = int(n_nodes[b])
+        coords_perm[b, :n] = r["x"][b, torch.as_tensor(order[b, :n], dtype=torch.long)]
+    save("e2e_perm_T20_b4n19.npz", **r, n_nodes=n_nodes, order=order, conn_in=conn_inj, elements=el, dist_mat=dm, adj_mat=am,
+         x_perm=coords_perm, logits=logits, argmax=torch.argmax(logits, -1), margin=margin,
+         order_dependent_entries=moved, gcn_weight_seed=4321)
+
 
 if __name__ == "__main__":
     main()

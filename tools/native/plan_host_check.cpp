@@ -1,7 +1,7 @@
 // Host-only driver of the plan builder's self-check (mcg_plan_host.cpp), built with AddressSanitizer + UBSan by
 // `make -C ml_conformer_generator_amd/csrc asan` (CPU only - GPU sanitizers are not available on this pool).
 //   plan_host_check <file>      one batch per line:  N cus edge_mt four_tile_units expect_ok n_1 n_2 ... n_B
-// Every batch goes through mcg_plan_build_host + mcg_plan_check_tables; the exit code is the number of batches whose
+// Every batch goes through mcg_plan_build_host + mcg_plan_check_tables and mcg_plan_range_cuts (1..6 parts); the exit code is the number of batches whose
 // outcome differs from `expect_ok` (sanitizer reports abort the process on their own).
 #include <cstdarg>
 #include <cstdio>
@@ -43,6 +43,14 @@ int main(int argc, char** argv) {
         g_err[0] = 0;
         const int rc = mcg_plan_check_tables((int)nn.size(), N, nn.data(), &o, cus, info);
         ++n_batches;
+        // the molecule-range cuts of the stream split: contiguous, non-empty, covering, for every number of parts
+        for (int parts = 1; parts <= 6; ++parts) {
+            const std::vector<int> cuts = mcg_plan_range_cuts((int)nn.size(), nn.data(), parts);
+            const int want = parts < (int)nn.size() ? parts : (int)nn.size();
+            bool ok = (int)cuts.size() == want + 1 && cuts.front() == 0 && cuts.back() == (int)nn.size();
+            for (size_t k = 0; ok && k + 1 < cuts.size(); ++k) ok = cuts[k + 1] > cuts[k];
+            if (!ok) { ++n_bad; fprintf(stderr, "batch %d: bad range cuts for %d parts\n", n_batches, parts); }
+        }
         for (int32_t v : nn) rows_total += (long)v * (v > 0 ? v - 1 : 0);
         if ((rc == 0) != (expect_ok != 0)) {
             ++n_bad;
