@@ -5,8 +5,8 @@
 
 A "step" is ONE call of the public path `MLConformerGenerator.generate_conformers_sharded` over one batch of
 synthetic input: the full ancestral sampler (T = 100 denoising steps = 101 EGNN calls), the device-side
-EDM->GCN hand-off, the AdjMatSeer GCN pass, bond argmax + write-back + validity proxy, the RCCL gather
-(N > 1), the final D2H copy and the host-side assembly of the molecule records.
+EDM->GCN hand-off, the AdjMatSeer GCN pass, bond argmax + write-back + validity proxy, the RCCL gather to
+rank 0 (N > 1), the final D2H copy and the host-side assembly of the molecule records.
 Workload at N = 1: BASELINE.json configs[1] (n_samples = 64, 27 heavy atoms, diffusion_steps = 100,
 fp32).  For N > 1 every rank generates its contiguous shard of 64 x N molecules (weak scaling, 64 per GPU)
 on its own weight replica; the results are gathered once with RCCL at the end of each step.
@@ -219,24 +219,33 @@ def make_generator(args, dev, dtype, sd, gsd):
     return gen
 
 
-def timed_passes(gen, ctx, n_total, n_atoms, variance, frag_kw, steps, warmup, fence, seed=7, ref_conformer=None):
+def timed_passes(gen, ctx, n_total, n_atoms, variance, frag_kw, steps, warmup, fence, seed=7, ref_conformer=None,
+                 vary_sizes=False):
     """`steps` timed calls of the public sharded path after `warmup` untimed ones.
+    `vary_sizes`: every pass (warm-up included) draws its molecule sizes from seed + pass index, the way a caller of a
+    ragged workload runs it (the reference's protocol generates for 1 000 different references,
+    research_scripts/evaluation.py:47-54,98-103): every timed pass then meets a size vector it has never seen and pays
+    the plan for it - host tables, uploads, workspace, HIP-graph capture - inside the timed region.  Otherwise every pass
+    re-draws the SAME sizes (fixed-size workloads: the draw is constant anyway).
     Returns (elapsed seconds on this rank, mean sampler ms per pass, whether EVERY coordinate this rank generated in the
     timed passes is finite - checked after the clock stops, last valid fraction)."""
     from ml_conformer_generator_amd.conformer_generator import HAVE_RDKIT     # (MMFF94 runs only where RDKit exists)
     sampler_ms = []
     kept = []
+    pass_index = [0]
 
     def one_pass():
         # sizes: CPU generator only (torch.manual_seed would also reseed every device generator and give all ranks
         # the same noise); noise: per-rank device generator, seed + rank, set inside the sharded path
-        torch.default_generator.manual_seed(seed)
+        torch.default_generator.manual_seed(seed + (pass_index[0] if vary_sizes else 0))
+        pass_index[0] += 1
         if ref_conformer is not None:
             mols = gen.generate_conformers_sharded(reference_conformer=ref_conformer, variance=variance, n_samples=n_total,
-                                                   seed=seed, optimise_geometry=HAVE_RDKIT, **frag_kw)
+                                                   seed=seed, optimise_geometry=HAVE_RDKIT, gather="rank0", **frag_kw)
         else:
             mols = gen.generate_conformers_sharded(reference_context=ctx, n_atoms=n_atoms, variance=variance,
-                                                   n_samples=n_total, seed=seed, optimise_geometry=HAVE_RDKIT, **frag_kw)
+                                                   n_samples=n_total, seed=seed, optimise_geometry=HAVE_RDKIT,
+                                                   gather="rank0", **frag_kw)
         torch.cuda.synchronize(gen.device)
         sampler_ms.append(gen._timing["sampler_start"].elapsed_time(gen._timing["sampler_end"]))
         if gen.last_batch is not None:
@@ -255,6 +264,42 @@ def timed_passes(gen, ctx, n_total, n_atoms, variance, frag_kw, steps, warmup, f
     elapsed = time.perf_counter() - t0
     finite = all(bool(torch.isfinite(x).all()) for x in kept)
     return elapsed, sum(sampler_ms) / max(1, len(sampler_ms)), finite, gen.last_valid_fraction
+
+
+def cold_call_cost(gen, dev, n_samples=256, n_atoms=27, variance=12, seed=9001):
+    """What the FIRST denoiser call over a never-seen size vector costs beyond a warm one: `plan_ms` = `EGNNDynamics.plan`
+    (host tables, uploads, workspace - `mcg_plan_create_ex`), `first_call_ms` = the first `mcg_egnn_dynamics` on it (HIP
+    graph capture + instantiate + launch), `warm_call_ms` = the second (graph replay); cold_call_ms = plan + first - warm.
+    Mean over three fresh size vectors; everything synchronised."""
+    dyn = gen.generative_model.dynamics
+    g = torch.Generator().manual_seed(seed)
+    rows = []
+    for _ in range(3):
+        lo, hi = max(n_atoms - variance, gen.min_n_nodes), min(n_atoms + variance, gen.max_n_nodes)
+        sizes = torch.randint(lo, hi + 1, (n_samples,), generator=g)
+        N = hi
+        nm = (torch.arange(N).unsqueeze(0) < sizes.unsqueeze(1)).float().unsqueeze(2).to(dev)
+        xh = torch.randn(n_samples, N, 11, device=dev) * nm
+        cx = torch.tensor([-0.99, -1.66, -1.66], device=dev).view(1, 1, 3).repeat(n_samples, N, 1) * nm
+        t = torch.full((n_samples,), 0.5, device=dev)
+        out = torch.empty_like(xh)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        plan = dyn.plan(sizes, N)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        dyn.run(plan, t, xh, cx, out)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        dyn.run(plan, t, xh, cx, out)
+        torch.cuda.synchronize(dev)
+        t3 = time.perf_counter()
+        rows.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3))
+    plan_ms, first_ms, warm_ms = (sum(r[k] for r in rows) / len(rows) for k in range(3))
+    return {"cold_call_ms": plan_ms + first_ms - warm_ms, "plan_ms": plan_ms, "first_call_ms": first_ms,
+            "warm_call_ms": warm_ms, "plans_cached": len(dyn._plans),
+            "what": "first denoiser call over a never-seen size vector minus a warm one: plan (host tables, uploads, "
+                    "workspace) + HIP-graph capture; mean of 3 fresh vectors"}
 
 
 def synthetic_fragment():
@@ -320,9 +365,9 @@ def config4_share(args, gsd, ctx, dev, fence):
     g4 = make_generator(a4, dev, "bf16", sd4, gsd)
     frag = synthetic_fragment()
     g4.set_diffusion_steps(10)
-    timed_passes(g4, ctx, 256, 27, 12, frag, 1, 0, fence)
+    timed_passes(g4, ctx, 256, 27, 12, frag, 1, 0, fence, seed=7)
     g4.set_diffusion_steps(250)
-    el, ms, fin, vf = timed_passes(g4, ctx, 256, 27, 12, frag, 1, 0, fence)
+    el, ms, fin, vf = timed_passes(g4, ctx, 256, 27, 12, frag, 1, 0, fence, seed=8)     # sizes the warm-up has not seen
     _, roof = edge_roofline(a4, g4, dev, "bf16")
     return {"workload": "configs[4] per-GPU share: n_samples=256, 27+-12 heavy atoms (ragged), fixed 8-atom fragment "
                         "(inpainting, resample_steps=1), diffusion_steps=250, bf16-operand MFMA HIP EGNN (fp32 "
@@ -594,11 +639,12 @@ def main():
     c3 = None
     if world > 1 and headline_default and not args.no_config3:
         # BASELINE configs[3]: 256 ragged molecules PER GPU (n_samples = 256 x N in total), every rank, 1 warm-up + 2 passes
-        el3, ms3, fin3, vf3 = timed_passes(gen, ctx, 256 * world, 27, 12, {}, 2, 1, fence)
+        el3, ms3, fin3, vf3 = timed_passes(gen, ctx, 256 * world, 27, 12, {}, 2, 1, fence, vary_sizes=True)
+        asm3 = gen.last_host_assembly_ms
         t3 = torch.tensor([el3, 0.0 if fin3 else 1.0], dtype=torch.float64,
                           device=dev if dist.get_backend() == "nccl" else torch.device("cpu"))
         dist.all_reduce(t3, op=dist.ReduceOp.MAX)
-        c3 = (float(t3[0].item()), ms3, float(t3[1].item()) == 0.0, vf3)
+        c3 = (float(t3[0].item()), ms3, float(t3[1].item()) == 0.0, vf3, asm3)
 
 
     if rank == 0:
@@ -633,7 +679,7 @@ def main():
                                    f"{'+-' + str(args.variance) if args.variance else ''} heavy atoms, "
                                    f"diffusion_steps={args.diffusion_steps}, " + mode_text,
                        "parallelism": (f"batch-sharded x{world}, " + ("RCCL" if backend == "nccl" else backend + " (dry run, ranks share the GPU)")
-                                       + " all_gather at end") if world > 1 else "single GPU",
+                                       + " gather to rank 0 at end (the only data-path collective)") if world > 1 else "single GPU",
                        "edge_rows_per_wave": 16 * plan.edge_mt, "real_edges": plan.n_real_edges,
                        "real_nodes": plan.n_real_nodes,
                        "weights": "synthetic, reference checkpoint layout, seed 1234, " +
@@ -666,11 +712,13 @@ def main():
                 "value": 256 * world * 2 / c3[0], "unit": "molecules/s", "n_gpus": world, "steps": 2, "warmup": 1,
                 "ms_per_step": c3[0] / 2 * 1e3, "egnn_step_ms_per_batch": c3[1] / (args.diffusion_steps + 1),
                 "valid_proxy_fraction": c3[3], "outputs_finite": c3[2], "roofline": roof3,
+                "host_assembly_ms": c3[4],
+                "sizes": "a different global size vector every pass (seed + pass index)",
                 "timing": "max over ranks, barrier + synchronize on both sides"}
             finite = finite and c3[2]
         if default_line and not args.no_config2:
             # BASELINE configs[2] (256 ragged molecules, 15..39 atoms) timed in the same run: 1 warm-up + 2 passes
-            el2, ms2, fin2, vf2 = timed_passes(gen, ctx, 256, 27, 12, {}, 2, 1, fence)
+            el2, ms2, fin2, vf2 = timed_passes(gen, ctx, 256, 27, 12, {}, 2, 1, fence, vary_sizes=True)
             tr2 = ts2 = None
             try:
                 e2 = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))["configs[2] shape: n_samples=256, n=27+-12"]
@@ -684,7 +732,10 @@ def main():
                 "workload": "configs[2] shape: n_samples=256, 27+-12 heavy atoms (ragged), diffusion_steps=100, " + mode_text,
                 "value": 256 * 2 / el2, "unit": "molecules/s", "steps": 2, "warmup": 1, "ms_per_step": el2 / 2 * 1e3,
                 "egnn_step_ms_per_batch": ms2 / (args.diffusion_steps + 1), "valid_proxy_fraction": vf2,
-                "outputs_finite": fin2, "roofline": roof2}
+                "outputs_finite": fin2, "roofline": roof2,
+                "sizes": "a different size vector every pass (seed + pass index): each timed pass builds its plan and captures "
+                         "its HIP graph inside the timed region",
+                "cold_call": cold_call_cost(gen, dev)}
         if default_line and not args.no_config0:
             out["config0_plumbing"] = config0_plumbing(args, gen, sd, gsd, dev, fence)
             finite = finite and out["config0_plumbing"]["outputs_finite"]

@@ -89,6 +89,12 @@ typedef struct mcg_plan_opts {
 #define MCG_ALL_FOUR_TILE 0x3fffffff
 int mcg_plan_create_ex(int B, int N, const int32_t* n_nodes_host, const mcg_plan_opts* opts, mcg_plan** out);
 void mcg_plan_destroy(mcg_plan* p);
+/* Plans take their device memory (one block of tables, one of workspace) from a per-device pool inside the library: the
+ * blocks of a destroyed plan are handed to the next one instead of going back to the driver, so a caller that meets a new
+ * size vector on every call (and evicts an old plan on every call) allocates nothing in steady state.
+ * stats_host[4] (may be NULL) = {bytes in use by live plans, bytes cached for reuse, driver allocations so far, pool hits so
+ * far} of the current device; trim != 0 first returns every cached block to the driver. */
+int mcg_pool_stats(int64_t* stats_host, int trim);
 /* Edge-kernel choice (exact-fp32 mode, edge_mt 1): -1 auto - the throughput kernel, whose workgroups take four 16-row
  * tiles each for every complete round of the chip and ONE tile each (columns split over the 4 waves) for the rest, i.e.
  * for the whole of a small batch; 0 = four-tile workgroups only; 1 = the stand-alone column-split kernel with per-wave

@@ -28,6 +28,7 @@ SIGNATURES: Dict[str, tuple] = {
     "mcg_plan_create": (_i, [_i, _i, _vp, _i, _pp]),
     "mcg_plan_create_ex": (_i, [_i, _i, _vp, _vp, _pp]),
     "mcg_plan_destroy": (None, [_vp]),
+    "mcg_pool_stats": (_i, [_vp, _i]),
     "mcg_plan_info": (_i, [_vp, _vp]),
     "mcg_plan_ranges": (_i, [_vp]),
     "mcg_plan_set_latency_mode": (_i, [_vp, _i]),

@@ -114,6 +114,7 @@ class MLConformerGenerator(torch.nn.Module):
         # (atomic_numbers, coords[n,3]) -> (order, connectivity) | None per molecule: see rdkit_order.py
         self.atom_order_provider = rdkit_order.default_provider() if atom_order_provider == "auto" else atom_order_provider
         self.last_batch = None       # tensors of the most recent generation (x, h, n_nodes, bond)
+        self.last_order = None
         self.last_valid_fraction = None   # share of the last batch that passed the validity proxy
         self.last_noise_seed = None       # device-generator seed of the last sharded call on this rank
         self.last_host_assembly_ms = None # host time of the last sharded call's D2H + molecule records
@@ -242,7 +243,8 @@ class MLConformerGenerator(torch.nn.Module):
         sym, valid = bond_writeback_hip(bond, el, n_nodes)
         if built is not None and not all(built):          # `MolFromXYZBlock` returned None: the reference drops it
             valid = valid & torch.tensor(built, dtype=torch.bool, device=valid.device)
-        self.last_batch = dict(x=x, h=h, n_nodes=n_nodes, elements=el, bond=bond, x_ordered=x_out, order=order)
+        self.last_batch = dict(x=x, h=h, n_nodes=n_nodes, elements=el, bond=bond, x_ordered=x_out)     # tensors only
+        self.last_order = order           # per-molecule atom orders the provider chose (None: generation order)
         return dict(x=x_out, elements=el.to(torch.int8), bond=sym, n_nodes=n_nodes.to(torch.int32),
                     valid=valid.to(torch.uint8))
 

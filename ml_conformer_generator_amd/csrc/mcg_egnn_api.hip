@@ -410,7 +410,7 @@ int mcg_egnn_dynamics(const mcg_egnn* m, mcg_plan* pl, const float* t, const flo
     if (pl->graph_exec && !pl->xh_stage && (key[0] != pl->g_key[0] || key[1] != pl->g_key[1] || key[2] != pl->g_key[2]) &&
         ++pl->key_changes >= 2) {
         float* st = nullptr;
-        if (hipMalloc((void**)&st, (2 * n_xh + n_ctx + 16) * sizeof(float)) == hipSuccess) {
+        if (mcg_dev_alloc((2 * n_xh + n_ctx + 16) * sizeof(float), (void**)&st) == MCG_OK) {
             pl->allocs.push_back(st);
             pl->xh_stage = st; pl->out_stage = st + n_xh; pl->ctx_stage = st + 2 * n_xh;
             if (getenv("MCG_VERBOSE")) fprintf(stderr, "[mcg] caller tensors move between calls: graph on staging buffers\n");

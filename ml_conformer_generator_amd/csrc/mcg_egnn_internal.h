@@ -120,7 +120,8 @@ struct mcg_plan {
     const UnitTables& units() const { return ut[(latency_mode == 0 && have_alt) ? 1 : 0]; }
     float *U = nullptr, *Ux = nullptr;
     bool x_pending = false;                 // host-side: Ux holds a coordinate update that has not been applied to x yet
-    std::vector<void*> allocs;
+    std::vector<void*> allocs;              // blocks of the plan pool (mcg_dev_alloc)
+    bool is_sub = false;                    // a molecule range of another plan
     // optional split into independent molecule ranges that run on separate HIP streams
     // (the latency-bound node GEMMs of one range overlap the edge kernels of the other)
     std::vector<mcg_plan*> subs;
@@ -147,6 +148,11 @@ struct mcg_plan {
     std::vector<EdgeTiming>* edge_timing = nullptr;       // pool of pre-created event pairs (no API call between launches)
     size_t* edge_timing_next = nullptr;                   // shared cursor into the pool
 };
+
+// device-memory pool of the plans (mcg_devmem.hip): blocks of destroyed plans are reused by new ones
+int mcg_dev_alloc(size_t bytes, void** out);
+void mcg_dev_free(void* p);
+void mcg_dev_trim();
 
 // small device-memory helpers shared by the model and plan builders
 int mcg_upload_f(const std::vector<float>& v, float** d);

@@ -35,54 +35,67 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, const m
         delete p;
         return MCG_ERR_ARG;
     }
-    int e = 0;
-    {
-        int* d = nullptr;
-        e |= mcg_upload_i(ij, &d);
-        p->row_ij = reinterpret_cast<int2*>(d);
-        p->allocs.push_back(d);
-    }
     if (!slots_ok) {
         mcg_set_error("mcg_plan_create: a molecule's edge rows span more than 8 tiles per atom (N > 114 is not supported)");
-        mcg_plan_destroy(p);
+        delete p;
         return MCG_ERR_ARG;
     }
-    e |= mcg_upload_i(node_slots, &p->node_slots);
-    p->allocs.push_back(p->node_slots);
-    e |= mcg_upload_i(nn, &p->n_nodes); e |= mcg_upload_i(node_off, &p->node_off); e |= mcg_upload_i(wave_poff, &p->wave_poff);
-    e |= mcg_upload_i(node_mol, &p->node_mol);
     int max_uslots = 0;
     for (int k = 0; k < n_sets; ++k) max_uslots = std::max(max_uslots, ht[k].n_uslots);
-    for (int k = 0; k < n_sets; ++k) {
+    for (int k = 0; k < n_sets; ++k)
         for (int& v : ht[k].node_slots) if (v < 0) v = max_uslots;       // the zero row (never written) is common to both sets
-        int* d = nullptr;
-        int* wi = nullptr;
-        e |= mcg_upload_i(ht[k].wg_info, &wi); e |= mcg_upload_i(ht[k].node_slots, &d);
+    // ---- ONE block of tables (one upload) and ONE block of workspace (one memset), both from the plan pool
+    // (mcg_devmem.hip): a caller of a ragged workload builds a plan per call, and 20 hipMalloc + 20 synchronous copies per
+    // plan were most of what its first call cost.
+    struct Tab { const std::vector<int>* v; int** dst; };
+    int *d_ij = nullptr, *d_wi[2] = {nullptr, nullptr}, *d_ns[2] = {nullptr, nullptr};
+    std::vector<Tab> tabs = {{&ij, &d_ij}, {&node_slots, &p->node_slots}, {&nn, &p->n_nodes}, {&node_off, &p->node_off},
+                             {&wave_poff, &p->wave_poff}, {&node_mol, &p->node_mol}};
+    for (int k = 0; k < n_sets; ++k) { tabs.push_back({&ht[k].wg_info, &d_wi[k]}); tabs.push_back({&ht[k].node_slots, &d_ns[k]}); }
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t tab_bytes = 0;
+    std::vector<size_t> tab_off;
+    for (const Tab& t : tabs) { tab_off.push_back(tab_bytes); tab_bytes += al(std::max<size_t>(t.v->size(), 1) * sizeof(int)); }
+    std::vector<char> stage(tab_bytes, 0);
+    for (size_t k = 0; k < tabs.size(); ++k)
+        if (!tabs[k].v->empty()) memcpy(stage.data() + tab_off[k], tabs[k].v->data(), tabs[k].v->size() * sizeof(int));
+    void* tab_block = nullptr;
+    if (int e = mcg_dev_alloc(tab_bytes, &tab_block)) { delete p; return e; }
+    p->allocs.push_back(tab_block);
+    if (hipMemcpy(tab_block, stage.data(), tab_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        mcg_set_error("mcg_plan_create: table upload failed");
+        mcg_plan_destroy(p);
+        return MCG_ERR_HIP;
+    }
+    for (size_t k = 0; k < tabs.size(); ++k) *tabs[k].dst = reinterpret_cast<int*>((char*)tab_block + tab_off[k]);
+    p->row_ij = reinterpret_cast<int2*>(d_ij);
+    for (int k = 0; k < n_sets; ++k) {
         mcg_plan::UnitTables& T = p->ut[k];
-        T.wg_info = reinterpret_cast<int4*>(wi);
-        T.node_slots = reinterpret_cast<int4*>(d);
+        T.wg_info = reinterpret_cast<int4*>(d_wi[k]);
+        T.node_slots = reinterpret_cast<int4*>(d_ns[k]);
         T.n_units = ht[k].n_units; T.n_full_wg = ht[k].n_full; T.n_uslots = ht[k].n_uslots; T.max_span = ht[k].span;
-        p->allocs.insert(p->allocs.end(), {(void*)wi, (void*)d});
     }
     p->have_alt = n_sets == 2;
-    if (e) { mcg_plan_destroy(p); return MCG_ERR_HIP; }
-    p->allocs.insert(p->allocs.end(), {(void*)p->n_nodes, (void*)p->node_off, (void*)p->wave_poff, (void*)p->node_mol});
     const size_t M1 = (size_t)(p->M > 0 ? p->M : 1);
     struct { float** ptr; size_t n; } bufs[] = {
         // (+64 floats: the bf16 kernels read activation rows up to k = 447, i.e. 16 floats past the last row)
         {&p->x, M1 * 4}, {&p->x0, M1 * 4}, {&p->h, M1 * HP + 64}, {&p->h2, M1 * HP + 64}, {&p->pab, M1 * 2 * HP + 64},
         {&p->agg, M1 * HP + 64}, {&p->t1, M1 * HP + 64}, {&p->P, (size_t)(p->n_pslots + 1) * HP}, {&p->Px, (size_t)(p->n_pslots + 1) * 4},
         {&p->U, (size_t)(max_uslots + 1) * HP + 64}, {&p->Ux, (size_t)(max_uslots + 1) * 4}};
-    for (auto& b : bufs) {
-        if (hipMalloc((void**)b.ptr, b.n * sizeof(float)) != hipSuccess || hipMemset(*b.ptr, 0, b.n * sizeof(float)) != hipSuccess) {
-            mcg_set_error("mcg_plan_create: out of device memory (%zu floats)", b.n);
-            (void)hipGetLastError();
-            if (*b.ptr) p->allocs.push_back(*b.ptr);
-            mcg_plan_destroy(p);
-            return MCG_ERR_HIP;
-        }
-        p->allocs.push_back(*b.ptr);
+    size_t ws_bytes = 0;
+    for (auto& b : bufs) ws_bytes += al(b.n * sizeof(float));
+    void* ws_block = nullptr;
+    if (int e = mcg_dev_alloc(ws_bytes, &ws_block)) { mcg_plan_destroy(p); return e; }
+    p->allocs.push_back(ws_block);
+    if (hipMemset(ws_block, 0, ws_bytes) != hipSuccess) {           // (synchronous: the plan's streams do not order with stream 0)
+        (void)hipGetLastError();
+        mcg_set_error("mcg_plan_create: workspace memset failed");
+        mcg_plan_destroy(p);
+        return MCG_ERR_HIP;
     }
+    size_t off = 0;
+    for (auto& b : bufs) { *b.ptr = reinterpret_cast<float*>((char*)ws_block + off); off += al(b.n * sizeof(float)); }
     *out = p;
     return MCG_OK;
 }
@@ -97,7 +110,9 @@ void mcg_plan_destroy(mcg_plan* p) {
     for (hipStream_t st : p->streams) (void)hipStreamDestroy(st);
     for (hipEvent_t e : p->ev_join) (void)hipEventDestroy(e);
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
-    for (void* q : p->allocs) (void)hipFree(q);
+    // the blocks go back to the plan pool, not to the driver: nothing may still be running on them (hipFree used to wait)
+    if (!p->allocs.empty() && !p->is_sub) (void)hipDeviceSynchronize();
+    for (void* q : p->allocs) mcg_dev_free(q);
     delete p;
 }
 
@@ -128,7 +143,7 @@ int mcg_plan_create_ex(int B, int N, const int32_t* n_nodes_host, const mcg_plan
 // graph staging buffer, capture stream and the optional split into molecule ranges
 static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, const mcg_plan_opts* opts) {
     const int n_ranges = opts ? opts->n_ranges : 0;
-    MCG_HIP(hipMalloc((void**)&p->t_buf, (size_t)B * sizeof(float)));
+    if (int e = mcg_dev_alloc((size_t)B * sizeof(float), (void**)&p->t_buf)) return e;
     p->allocs.push_back(p->t_buf);
     MCG_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
     // Split the batch into `parts` molecule ranges of ~equal edge count, one HIP stream each: the launch-bound node GEMMs
@@ -150,6 +165,7 @@ static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, c
         const int b0 = cuts[k], b1 = cuts[k + 1];
         mcg_plan* sub = nullptr;
         if (int e = plan_create_single(b1 - b0, N, n_nodes_host + b0, opts, &sub)) return e;
+        sub->is_sub = true;            // destroyed with its parent, which synchronises the device once for all of them
         p->subs.push_back(sub);
         p->sub_b0.push_back(b0);
         hipStream_t st; hipEvent_t ev;

@@ -48,6 +48,12 @@ def world_and_rank(group=None) -> Tuple[int, int]:
     return 1, 0
 
 
+def _solo(world: int) -> bool:
+    """A 1-rank world skips every collective - unless MCG_FORCE_COLLECTIVE=1 asks for them (RCCL smoke check on one GPU:
+    tools/rccl_one_rank_check.py)."""
+    return world == 1 and not os.environ.get("MCG_FORCE_COLLECTIVE")
+
+
 def _collective_device(group=None) -> torch.device:
     """Where a tensor has to live for this group's collectives: RCCL moves device memory, gloo host memory."""
     if dist.get_backend(group) == "nccl":
@@ -59,7 +65,7 @@ def draw_global_sizes(n_samples: int, min_n_nodes: int, max_n_nodes: int, group=
     """The sizes of the WHOLE batch [n_samples] int64 (CPU), identical on every rank: drawn on rank 0 with
     the reference's draw from the CPU global RNG, then broadcast."""
     world, rank = world_and_rank(group)
-    if world == 1:
+    if _solo(world) or not (dist.is_available() and dist.is_initialized()):
         return torch.randint(min_n_nodes, max_n_nodes + 1, (n_samples,))
     dev = _collective_device(group)
     if rank == 0:
@@ -81,8 +87,8 @@ def gather_results(local: Dict[str, torch.Tensor], n_samples: int, group=None, d
     if not dist.is_available() or not dist.is_initialized():
         return local
     world = dist.get_world_size(group)
-    if world == 1 and not os.environ.get("MCG_FORCE_COLLECTIVE"):
-        return local          # (MCG_FORCE_COLLECTIVE=1: run the collective on a 1-rank group - RCCL smoke check)
+    if _solo(world):
+        return local
     rank = dist.get_rank(group)
     sizes = shard_sizes(n_samples, world)
     cap = max(sizes)
@@ -119,7 +125,7 @@ def draw_base_seed(group=None) -> int:
     """A noise base seed that is identical on every rank: drawn on rank 0 from the CPU global RNG (after the size
     draw, so the sizes stay what a single-process run draws) and broadcast."""
     world, rank = world_and_rank(group)
-    if world == 1:
+    if _solo(world) or not (dist.is_available() and dist.is_initialized()):
         return int(torch.randint(0, 2 ** 31 - 1, (1,)))
     dev = _collective_device(group)
     t = torch.randint(0, 2 ** 31 - 1, (1,)).to(dev) if rank == 0 else torch.zeros(1, dtype=torch.long, device=dev)
@@ -131,7 +137,7 @@ def draw_base_seed(group=None) -> int:
 def exchange_status(ok: bool, group=None) -> List[bool]:
     """One byte per rank, all-gathered BEFORE the result tensors: which ranks finished their shard."""
     world, _ = world_and_rank(group)
-    if world == 1:
+    if _solo(world) or not (dist.is_available() and dist.is_initialized()):
         return [ok]
     dev = _collective_device(group)
     mine = torch.tensor([1 if ok else 0], dtype=torch.uint8, device=dev)

@@ -99,7 +99,8 @@ class EGNNDynamics(torch.nn.Module):
         self.device = torch.device(device)
         self._h = C.c_void_p()
         self.compute_dtype = "f32"
-        self._plans: Dict[tuple, BatchPlan] = {}
+        self._plans: Dict[tuple, BatchPlan] = {}      # LRU (dict order = recency), `plan_cache_size` entries
+        self.plan_cache_size = 8
         self._edge_mask_ok = None          # (weakref to the last verified edge_mask tensor, its version, its plan)
 
     # -- weights ------------------------------------------------------------------
@@ -166,11 +167,15 @@ class EGNNDynamics(torch.nn.Module):
             n_ranges = 2 if int((nn * (nn - 1)).sum()) >= 1500 * 16 else 1
         key = (int(max_n_nodes), int(edge_mt), int(four_tile_units), int(n_ranges), tuple(int(v) for v in n_nodes.reshape(-1).tolist()))
         p = self._plans.get(key)
-        if p is None:
-            if len(self._plans) >= 4:
-                self._plans.pop(next(iter(self._plans)))
-            p = BatchPlan(n_nodes, max_n_nodes, self.device, edge_mt, n_ranges, four_tile_units)
-            self._plans[key] = p
+        if p is not None:
+            self._plans[key] = self._plans.pop(key)          # least-recently-USED goes first: a hit moves to the back
+            return p
+        # A ragged caller meets a new size vector on every call: the oldest plan goes (its device blocks return to the
+        # library's plan pool and are handed to the new plan - no driver allocation in steady state).
+        while len(self._plans) >= max(1, self.plan_cache_size):
+            self._plans.pop(next(iter(self._plans)))
+        p = BatchPlan(n_nodes, max_n_nodes, self.device, edge_mt, n_ranges, four_tile_units)
+        self._plans[key] = p
         return p
 
     def check_edge_mask(self, plan: BatchPlan, edge_mask) -> None:

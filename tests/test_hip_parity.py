@@ -1031,7 +1031,7 @@ def test_generate_path_with_injected_atom_order_vs_reference_golden(sampler_fact
     assert torch.equal(h.cpu().to(torch.int64), g["h"].to(torch.int64))
     x_err = float((x.cpu() - g["x"]).abs().max())
     n_nodes = g["n_nodes"]
-    order, conn = [r.tolist() for r in g["order"]], list(g["conn_in"].numpy())
+    order, conn = [r.tolist() for r in g["order"]], list(np.asarray(g["conn_in"]))
     el, dm, am, xo = prepare_adj_mat_seer_input_hip(x, h, n_nodes.to(DEV), order=order, connectivity=conn, with_coords=True)
     assert torch.equal(el.cpu(), g["elements"]) and torch.equal(am.cpu(), g["adj_mat"])
     assert float((dm.cpu() - g["dist_mat"]).abs().max()) <= 4.0 * x_err + 1e-5
@@ -1701,3 +1701,60 @@ def test_sharded_path_on_one_rank_rccl_in_a_fresh_process():
     print(line)
     assert line["backend"] == "nccl" and line["world"] == 1 and line["identical_to_unsharded"] and line["finite"]
     assert len(line["sizes"]) == 8 and 17 <= min(line["sizes"]) and max(line["sizes"]) <= 23
+
+
+def test_new_size_vector_every_call_reuses_pooled_plan_memory(edm_sd):
+    """A ragged caller meets a never-seen size vector on every call (reference protocol: 1 000 different references,
+    research_scripts/evaluation.py:98-103): with a bounded LRU plan cache every call builds a plan and evicts one.  The
+    plans' device blocks come from the library's pool (csrc/mcg_devmem.hip), so after the first few calls the driver is not
+    asked for memory any more and free device memory stays flat; a plan built on RECYCLED blocks computes bit-identical
+    results to one built on fresh driver memory."""
+    import numpy as np
+    from ml_conformer_generator_amd import _lib
+    from ml_conformer_generator_amd.egnn import EGNNDynamics
+    L = _lib.lib()
+
+    def stats(trim=0):
+        st = np.zeros(4, dtype=np.int64)
+        _lib.check(L.mcg_pool_stats(st.ctypes.data, trim), "mcg_pool_stats")
+        return [int(v) for v in st]
+
+    d = EGNNDynamics(device=DEV)
+    d.load_reference_state_dict(edm_sd)
+    d.plan_cache_size = 3
+    g = torch.Generator().manual_seed(123)
+    B, N = 96, 39
+    free_mem, allocs, outs, inputs = [], [], [], []
+    for k in range(18):
+        sizes = torch.randint(15, 40, (B,), generator=g)
+        nm = (torch.arange(N).unsqueeze(0) < sizes.unsqueeze(1)).float().unsqueeze(2).to(DEV)
+        xh = torch.randn(B, N, 11, generator=g).to(DEV) * nm
+        cx = torch.randn(B, 1, 3, generator=g).repeat(1, N, 1).to(DEV) * nm
+        t = torch.full((B,), 0.4, device=DEV)
+        plan = d.plan(sizes, N)
+        out = d.run(plan, t, xh, cx)
+        torch.cuda.synchronize(DEV)
+        assert bool(torch.isfinite(out).all())
+        free_mem.append(torch.cuda.mem_get_info(DEV)[0])
+        allocs.append(stats()[2])
+        if k >= 16:
+            outs.append(out.clone()); inputs.append((sizes, t, xh, cx))
+        del plan
+    assert len(d._plans) == 3
+    assert allocs[-1] - allocs[9] <= 2, allocs                      # steady state: (almost) no driver allocation per new plan
+    assert stats()[3] > 20                                          # ... because the pool serves them
+    assert free_mem[9] - free_mem[-1] <= 96 << 20, free_mem         # flat device memory (a stray new size class at most)
+    # LRU, not FIFO: a plan that keeps being used survives newer ones
+    keep_sizes, t, xh, cx = inputs[0]
+    key_plan = d.plan(keep_sizes, N)
+    for k in range(4):
+        d.plan(torch.randint(15, 40, (B,), generator=g), N)
+        assert d.plan(keep_sizes, N) is key_plan
+    # recycled blocks vs fresh driver memory: bit-identical
+    d._plans.clear()
+    import gc
+    gc.collect()
+    stats(trim=1)
+    assert stats()[1] == 0
+    for (sizes, t, xh, cx), ref in zip(inputs, outs):
+        assert torch.equal(d.run(d.plan(sizes, N), t, xh, cx), ref)

@@ -5,8 +5,7 @@ also be run by hand on a GPU box).
 Initialises a 1-rank `nccl` (= RCCL on ROCm) group on cuda:0 with MCG_FORCE_COLLECTIVE=1, so that
 `generate_conformers_sharded` really issues its collectives on the device - the status byte (`all_gather_into_tensor`),
 the result `all_gather_into_tensor` / `gather` - instead of short-cutting a 1-rank world, and compares what comes back with
-the unsharded call under the same seeds.  Prints one JSON line.  (The size / seed broadcasts are world > 1 only; they go
-through the same `_collective_device` and are covered by the world-2 gloo tests.)
+the unsharded call under the same seeds.  Prints one JSON line.  The size / seed broadcasts are exercised the same way.
 """
 import json
 import os
@@ -41,6 +40,14 @@ def main() -> int:
         results[gather] = {k: v.clone() for k, v in gen.last_batch.items() if torch.is_tensor(v)}
         out[f"host_assembly_ms_{gather}"] = gen.last_host_assembly_ms
     dist.barrier()
+    # the two control-plane broadcasts (sizes, base seed) as device tensors through RCCL
+    from ml_conformer_generator_amd import distributed as D
+    torch.manual_seed(5)
+    drawn = D.draw_global_sizes(8, 17, 23)
+    torch.manual_seed(5)
+    out["broadcast_sizes_ok"] = bool(torch.equal(drawn, torch.randint(17, 24, (8,))))
+    out["broadcast_seed"] = D.draw_base_seed()
+    out["status_exchange"] = D.exchange_status(True)
     # the unsharded call under the same seeds (size draw from the CPU global RNG, noise seed + rank 0)
     torch.manual_seed(21)
     torch.cuda.manual_seed(11)
@@ -52,7 +59,7 @@ def main() -> int:
     out["finite"] = bool(torch.isfinite(plain["x"]).all())
     dist.destroy_process_group()
     print(json.dumps(out))
-    return 0 if same and out["finite"] else 1
+    return 0 if same and out["finite"] and out["broadcast_sizes_ok"] and out["status_exchange"] == [True] else 1
 
 
 if __name__ == "__main__":
