@@ -2,7 +2,7 @@
 // (the reference's evaluation protocol generates for 1 000 different references, research_scripts/evaluation.py:98-103), i.e.
 // a new plan per call and - with a bounded plan cache - a destroyed one per call.  hipMalloc / hipFree cost 0.1-1 ms each
 // and hipFree synchronises the device; a plan used to make ~20 of each.  Plans now take TWO blocks (tables, workspace) from
-// this pool: freed blocks are kept per device in size classes (1/8-octave rounding, <= 12.5 % slack) and handed out again,
+// this pool: freed blocks are kept per device in size classes (1/8-octave rounding; a request takes the smallest cached block within 1.5x of it) and handed out again,
 // so after the first few calls a new plan allocates nothing and device memory stays flat.  288 GB of HBM per GPU: the cap on
 // cached bytes (4 GiB per device) is about what 20 plans of the 256-molecule ragged workload hold.
 #include "mcg_egnn_internal.h"
@@ -47,12 +47,15 @@ int mcg_dev_alloc(size_t bytes, void** out) {
     {
         std::lock_guard<std::mutex> lk(g_mu);
         DevPool& P = g_pools[dev];
-        auto it = P.free_blocks.find(cls);
-        if (it != P.free_blocks.end()) {
+        // best fit: the smallest cached block that holds the request, as long as it is not more than 1.5x too large
+        // (ragged size vectors of one workload differ by a few per cent: their blocks serve one another)
+        auto it = P.free_blocks.lower_bound(cls);
+        if (it != P.free_blocks.end() && it->first <= cls + cls / 2) {
+            const size_t got = it->first;
             *out = it->second;
             P.free_blocks.erase(it);
-            P.cached -= cls; P.in_use += cls; ++P.n_pool_hits;
-            P.live[*out] = cls;
+            P.cached -= got; P.in_use += got; ++P.n_pool_hits;
+            P.live[*out] = got;
             return MCG_OK;
         }
     }

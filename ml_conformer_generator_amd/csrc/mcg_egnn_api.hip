@@ -239,8 +239,8 @@ int gemm(const float* A1, int lda1, int K1, const float* A2, int lda2, int K2, c
     McgGemmArgs g{};
     g.A1 = A1; g.lda1 = lda1; g.K1 = K1; g.A2 = A2; g.lda2 = lda2; g.K2 = K2; g.Bp = Bp; g.bias = bias;
     g.resid = resid; g.ldr = ldr; g.C = C; g.ldc = ldc; g.M = M; g.n_tiles = n_tiles; g.n_store = n_store; g.act = act;
-    if (side && side->x_pending && !Bp16 && !Bp16x3) {
-        g.side_u = side->Ux; g.side_slots = side->units().node_slots; g.side_x = side->x; g.side_M = side->M;
+    if (side && side->x_pending && !Bp16x3) {       // fp32 and bf16 kernels carry the side job; the split-operand one does not
+        g.side_u = side->pending_u; g.side_slots = side->pending_slots; g.side_x = side->x; g.side_M = side->M;
         side->x_pending = false;
     }
     if (rows16 > 0 && !Bp16 && !Bp16x3) {
@@ -262,7 +262,7 @@ int gemm(const float* A1, int lda1, int K1, const float* A2, int lda2, int K2, c
         MCG_HIP(mcg_gemm_x6_launch(g, s, opt ? opt->gemm_x6_rn : 0));
         return MCG_OK;
     }
-    if (Bp16) g.Bp = reinterpret_cast<const float*>(Bp16);
+    if (Bp16) { g.Bp = reinterpret_cast<const float*>(Bp16); g.a2_rows = a2_rows; g.a2_nsum = a2_nsum; }
     MCG_HIP(mcg_gemm_launch(g, s, Bp16 != nullptr, opt ? opt->gemm_rn : 0));
     return MCG_OK;
 }
@@ -274,7 +274,7 @@ static int pab_rows16(int M) { return (long)((M + 15) / 16) * ((2 * NT + 2) / 3)
 // pending coordinate update (workgroup-level sums in pl->Ux) applied by a stand-alone launch
 int apply_pending_x(mcg_plan* pl, hipStream_t s) {
     if (!pl->x_pending) return MCG_OK;
-    hipLaunchKernelGGL(k_coord_apply2, dim3((pl->M * 4 + 255) / 256), dim3(256), 0, s, pl->Ux, pl->units().node_slots, pl->M, pl->x);
+    hipLaunchKernelGGL(k_coord_apply2, dim3((pl->M * 4 + 255) / 256), dim3(256), 0, s, pl->pending_u, pl->pending_slots, pl->M, pl->x);
     MCG_HIP(hipGetLastError());
     pl->x_pending = false;
     return MCG_OK;
@@ -289,9 +289,11 @@ int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s, bool keep
     const bool x6g = m->x6 && m->x6_gemm;
     const bool wgc = edge_wgc(m, pl);
     const bool f32 = !lp && !x6g;
-    // (a pending coordinate update of the previous block rides along with this launch; the other operand modes'
-    //  GEMM kernels have no side job: apply it first)
-    if (!f32) { if (int e = apply_pending_x(pl, s)) return e; }
+    // bf16 mode: the node GEMM gathers an atom's per-unit partial sums (<= 4 rows of P) itself - no combine launch
+    const bool pgather = lp && !wgc && pl->pslots4 && pl->pspan <= 4 && !keep_agg;
+    // (a pending coordinate update of the previous block rides along with this launch; the split-operand GEMM kernel has
+    //  no side job: apply it first)
+    if (x6g) { if (int e = apply_pending_x(pl, s)) return e; }
     if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
                      MCG_ACT_NONE, s, lp ? E.pab_Bp16 : nullptr, x6g ? E.pab_Bp16x3 : nullptr, pl, pab_rows16(M), nullptr, 2, m)) return e;
     if (int e = apply_pending_x(pl, s)) return e;              // (only if the GEMM above could not carry it)
@@ -302,6 +304,8 @@ int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s, bool keep
     } else if (wgc) {
         hipLaunchKernelGGL(k_gather_agg2, dim3(M), dim3(128), 0, s, pl->U, pl->units().node_slots, pl->agg);
         MCG_HIP(hipGetLastError());
+    } else if (pgather) {
+        gather = pl->pslots4;                                   // rows of P, summed and divided by 100 in the bf16 GEMM's A-loader
     } else {
         // (reading the per-wave partials directly in the node GEMM's A-loader was tried: the 4-way gather costs the
         //  GEMM as much as the ~6 us combine launch it saves at config 2 and more at config 3)
@@ -311,8 +315,9 @@ int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s, bool keep
     // node_mlp: h + W4 silu(W3 [h | agg] + b3) + b4   (egnn.py:30-34,66-67).  Wave tiles of 3 column tiles x 16 rows
     // balance these two GEMMs on 1024 SIMDs at config 2 (972 waves); larger batches take 32-row tiles (gemm()).
     const int r16 = f32 ? 3 : 0;
-    if (int e = gemm(pl->h, HP, H, gather ? pl->U : pl->agg, HP, H, Nl.w3_Bp, Nl.b3, nullptr, 0, pl->t1, HP, M, NT, HP, MCG_ACT_SILU, s,
-                     lp ? Nl.w3_Bp16 : nullptr, x6g ? Nl.w3_Bp16x3 : nullptr, nullptr, gather ? 3 : r16, gather, pl->units().max_span, m)) return e;
+    if (int e = gemm(pl->h, HP, H, pgather ? pl->P : gather ? pl->U : pl->agg, HP, H, Nl.w3_Bp, Nl.b3, nullptr, 0, pl->t1, HP, M, NT, HP,
+                     MCG_ACT_SILU, s, lp ? Nl.w3_Bp16 : nullptr, x6g ? Nl.w3_Bp16x3 : nullptr, nullptr, (gather && !pgather) ? 3 : r16, gather,
+                     pgather ? pl->pspan : pl->units().max_span, m)) return e;
     if (int e = gemm(pl->t1, HP, H, nullptr, 0, 0, Nl.w4_Bp, Nl.b4, pl->h, HP, pl->h2, HP, M, NT, HP, MCG_ACT_NONE, s,
                      lp ? Nl.w4_Bp16 : nullptr, x6g ? Nl.w4_Bp16x3 : nullptr, nullptr, r16, nullptr, 2, m)) return e;
     std::swap(pl->h, pl->h2);
@@ -329,6 +334,12 @@ int run_equiv(const mcg_egnn* m, mcg_plan* pl, int block, hipStream_t s) {
     if (int e = run_edge(pl, E, true, pl->Px, s, m->bf16, m->x6, wgc)) return e;
     if (wgc) {
         pl->x_pending = true;          // applied by the next launch that can carry it (next block's first GEMM / k_output)
+        pl->pending_u = pl->Ux; pl->pending_slots = pl->units().node_slots;
+        return MCG_OK;
+    }
+    if (m->bf16 && pl->pslots4 && pl->pspan <= 4) {     // bf16 mode: the same, on the per-unit partial sums
+        pl->x_pending = true;
+        pl->pending_u = pl->Px; pl->pending_slots = pl->pslots4;
         return MCG_OK;
     }
     const int threads = M * 4;
@@ -374,8 +385,8 @@ static int dynamics_launch(const mcg_egnn* m, mcg_plan* pl, const float* t, cons
     }
     // (the last block's coordinate update is folded into the output head)
     hipLaunchKernelGGL(k_output, dim3((pl->M + pl->B + 3) / 4), dim3(256), 0, s, pl->h, pl->x, pl->x0, pl->n_nodes, pl->node_off,
-                       pl->node_mol, pl->M, pl->B, pl->N, m->out_w, m->out_b, out, pl->x_pending ? pl->Ux : (const float*)nullptr,
-                       pl->x_pending ? pl->units().node_slots : (const int4*)nullptr);
+                       pl->node_mol, pl->M, pl->B, pl->N, m->out_w, m->out_b, out, pl->x_pending ? pl->pending_u : (const float*)nullptr,
+                       pl->x_pending ? pl->pending_slots : (const int4*)nullptr);
     MCG_HIP(hipGetLastError());
     pl->x_pending = false;
     return MCG_OK;

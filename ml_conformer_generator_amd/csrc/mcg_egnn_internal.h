@@ -119,7 +119,14 @@ struct mcg_plan {
     bool have_alt = false;                  // [1]: four-tile units only (latency_mode 0), built when it differs from [0]
     const UnitTables& units() const { return ut[(latency_mode == 0 && have_alt) ? 1 : 0]; }
     float *U = nullptr, *Ux = nullptr;
-    bool x_pending = false;                 // host-side: Ux holds a coordinate update that has not been applied to x yet
+    // per-unit partial sums of the 64-row / 16-row bf16 and the column-split kernels (P / Px, one row per unit and atom, NOT
+    // divided by 100): an atom's first four slots as one int4 (unused = the zero row n_pslots), so that the bf16 node GEMM
+    // can gather them like the fp32 one gathers U and the coordinate update can ride along as a side job
+    int4* pslots4 = nullptr;
+    int pspan = 0;                          // most slots any atom has; the gathers need <= 4
+    bool x_pending = false;                 // host-side: a coordinate update sits in pending_u / pending_slots, not yet applied to x
+    const float* pending_u = nullptr;       // Ux (workgroup-level sums) or Px (per-unit partial sums)
+    const int4* pending_slots = nullptr;
     std::vector<void*> allocs;              // blocks of the plan pool (mcg_dev_alloc)
     bool is_sub = false;                    // a molecule range of another plan
     // optional split into independent molecule ranges that run on separate HIP streams

@@ -48,9 +48,22 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, const m
     // (mcg_devmem.hip): a caller of a ragged workload builds a plan per call, and 20 hipMalloc + 20 synchronous copies per
     // plan were most of what its first call cost.
     struct Tab { const std::vector<int>* v; int** dst; };
-    int *d_ij = nullptr, *d_wi[2] = {nullptr, nullptr}, *d_ns[2] = {nullptr, nullptr};
+    int *d_ij = nullptr, *d_wi[2] = {nullptr, nullptr}, *d_ns[2] = {nullptr, nullptr}, *d_ps4 = nullptr;
+    // an atom's first four per-unit slots as one int4 (unused = the zero row behind the last slot)
+    std::vector<int> ps4((size_t)std::max(p->M, 1) * 4, p->n_pslots);
+    p->pspan = 0;
+    for (int v = 0; v < p->M; ++v) {
+        int cnt = 0;
+        for (int k = 0; k < 8; ++k) {
+            const int sl = node_slots[(size_t)v * 8 + k];
+            if (sl < 0) continue;
+            if (cnt < 4) ps4[(size_t)v * 4 + cnt] = sl;
+            ++cnt;
+        }
+        p->pspan = std::max(p->pspan, cnt);
+    }
     std::vector<Tab> tabs = {{&ij, &d_ij}, {&node_slots, &p->node_slots}, {&nn, &p->n_nodes}, {&node_off, &p->node_off},
-                             {&wave_poff, &p->wave_poff}, {&node_mol, &p->node_mol}};
+                             {&wave_poff, &p->wave_poff}, {&node_mol, &p->node_mol}, {&ps4, &d_ps4}};
     for (int k = 0; k < n_sets; ++k) { tabs.push_back({&ht[k].wg_info, &d_wi[k]}); tabs.push_back({&ht[k].node_slots, &d_ns[k]}); }
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     size_t tab_bytes = 0;
@@ -70,6 +83,7 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, const m
     }
     for (size_t k = 0; k < tabs.size(); ++k) *tabs[k].dst = reinterpret_cast<int*>((char*)tab_block + tab_off[k]);
     p->row_ij = reinterpret_cast<int2*>(d_ij);
+    p->pslots4 = reinterpret_cast<int4*>(d_ps4);
     for (int k = 0; k < n_sets; ++k) {
         mcg_plan::UnitTables& T = p->ut[k];
         T.wg_info = reinterpret_cast<int4*>(d_wi[k]);
@@ -81,7 +95,7 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, const m
     struct { float** ptr; size_t n; } bufs[] = {
         // (+64 floats: the bf16 kernels read activation rows up to k = 447, i.e. 16 floats past the last row)
         {&p->x, M1 * 4}, {&p->x0, M1 * 4}, {&p->h, M1 * HP + 64}, {&p->h2, M1 * HP + 64}, {&p->pab, M1 * 2 * HP + 64},
-        {&p->agg, M1 * HP + 64}, {&p->t1, M1 * HP + 64}, {&p->P, (size_t)(p->n_pslots + 1) * HP}, {&p->Px, (size_t)(p->n_pslots + 1) * 4},
+        {&p->agg, M1 * HP + 64}, {&p->t1, M1 * HP + 64}, {&p->P, (size_t)(p->n_pslots + 1) * HP + 64}, {&p->Px, (size_t)(p->n_pslots + 1) * 4},
         {&p->U, (size_t)(max_uslots + 1) * HP + 64}, {&p->Ux, (size_t)(max_uslots + 1) * 4}};
     size_t ws_bytes = 0;
     for (auto& b : bufs) ws_bytes += al(b.n * sizeof(float));

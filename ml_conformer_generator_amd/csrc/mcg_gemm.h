@@ -103,13 +103,19 @@ static void mcg_pack_b16(std::vector<uint16_t>& dst, int K, int n_tiles, F value
                 }
 }
 
-template <int RN>
+// GATHER (0 / 2 / 4): row r of the SECOND K segment is (A2[s.x] + A2[s.y] (+ A2[s.z] + A2[s.w])) / 100 with s = a2_rows[r] -
+// the per-unit partial sums of the 64-row edge kernel (one row per unit and atom, NOT yet divided by 100; unused slots
+// name the common zero row), i.e. the aggregate of egnn.py:59-64,435 read straight from the edge kernel's output: no
+// combine launch.  Workgroups beyond `gemm_blocks` run the coordinate-update side job like the fp32 kernels.
+template <int RN, int GATHER = 0>
 __global__ __launch_bounds__(256) void mcg_gemm_bf16_kernel(McgGemmArgs p) {
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int wave_cols = (p.n_tiles + RN - 1) / RN;
-    const int wlin = MCG_GEMM_BLOCK(blockIdx.x, gridDim.x) * 4 + wid;
+    const int nblk = p.gemm_blocks > 0 ? p.gemm_blocks : (int)gridDim.x;        // (+ side-job workgroups behind them)
+    if ((int)blockIdx.x >= nblk) { mcg_gemm_side_job(p, (int)blockIdx.x - nblk); return; }
+    const int wlin = MCG_GEMM_BLOCK(blockIdx.x, nblk) * 4 + wid;
     if (wlin >= ((p.M + 31) / 32) * wave_cols) return;
     const int row0 = (wlin / wave_cols) * 32;
     const int nt0 = (wlin % wave_cols) * RN;
@@ -152,40 +158,51 @@ __global__ __launch_bounds__(256) void mcg_gemm_bf16_kernel(McgGemmArgs p) {
     }
 
     const bf16x8* bseg = reinterpret_cast<const bf16x8*>(p.Bp);
-#pragma unroll 1
-    for (int seg = 0; seg < 2; ++seg) {
-        const float* A = seg == 0 ? p.A1 : p.A2;
-        const int K = seg == 0 ? p.K1 : p.K2;
-        const int lda = seg == 0 ? p.lda1 : p.lda2;
-        if (K == 0) continue;
-        const float* a0 = A + (size_t)rA[0] * lda + 8 * g;
-        const float* a1 = A + (size_t)rA[1] * lda + 8 * g;
+    auto ld = [](const __amdgpu_buffer_rsrc_t& r, unsigned v, int so) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)v, so, 0); };
+    // one K segment whose row r of A is the sum of NS rows (NS = 1: the row itself) scaled by `scale_div100`
+    auto segment = [&](auto ns_tag, const float* A, int K, int lda, const int (&ra)[2][4]) {
+        constexpr int NS = decltype(ns_tag)::value;
         const int blocks = mcg_kblocks16(K);
         const size_t bstride = (size_t)p.n_tiles * 64;        // bf16x8 elements per k-block
-        const bf16x8* bq = bseg + (size_t)nt0 * 64 + lane;
         // 3-deep register ring, same discipline as the fp32 kernel (pinned order, unconditional loads)
-        f32x4 Ar[3][2][2];
+        f32x4 Ar[3][2][NS][2];
         bf16x8 Br[3][RN];
         const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, 0xffffffff, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8*>(bseg), 0, 0xffffffff, 0x00020000);
-        const unsigned oa0 = (unsigned)(rA[0] * lda + 8 * g) * 4u, oa1 = (unsigned)(rA[1] * lda + 8 * g) * 4u;
+        unsigned oa[2][NS];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < NS; ++q) oa[m][q] = (unsigned)(ra[m][q] * lda + 8 * g) * 4u;
         unsigned obn[RN];
 #pragma unroll
         for (int n = 0; n < RN; ++n) obn[n] = (unsigned)((nt0 + ncl[n]) * 64 + lane) * 16u;
         const int bbytes = p.n_tiles * 64 * 16;
-        auto ld = [](const __amdgpu_buffer_rsrc_t& r, unsigned v, int so) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)v, so, 0); };
         auto load_block = [&](int slot, int kb) {
             kb = kb < blocks ? kb : blocks - 1;
-            Ar[slot][0][0] = __builtin_bit_cast(f32x4, ld(rs_a, oa0, 128 * kb));
-            Ar[slot][0][1] = __builtin_bit_cast(f32x4, ld(rs_a, oa0, 128 * kb + 16));
-            Ar[slot][1][0] = __builtin_bit_cast(f32x4, ld(rs_a, oa1, 128 * kb));
-            Ar[slot][1][1] = __builtin_bit_cast(f32x4, ld(rs_a, oa1, 128 * kb + 16));
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < NS; ++q) {
+                    Ar[slot][m][q][0] = __builtin_bit_cast(f32x4, ld(rs_a, oa[m][q], 128 * kb));
+                    Ar[slot][m][q][1] = __builtin_bit_cast(f32x4, ld(rs_a, oa[m][q], 128 * kb + 16));
+                }
 #pragma unroll
             for (int n = 0; n < RN; ++n) Br[slot][n] = __builtin_bit_cast(bf16x8, ld(rs_b, obn[n], kb * bbytes));
         };
+        auto row_value = [&](int slot, int m, int half) -> f32x4 {
+            f32x4 v = Ar[slot][m][0][half];
+            if constexpr (NS > 1) {
+#pragma unroll
+                for (int q = 1; q < NS; ++q) v += Ar[slot][m][q][half];     // slot order = unit order: fixed, deterministic
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = mcg_div100(v[r]);       // the aggregate's / normalization_factor (egnn.py:435)
+            }
+            return v;
+        };
         auto compute = [&](int slot) {
-            const bf16x8 A0 = mcg_pack_bf16(Ar[slot][0][0], Ar[slot][0][1]);
-            const bf16x8 A1 = mcg_pack_bf16(Ar[slot][1][0], Ar[slot][1][1]);
+            const bf16x8 A0 = mcg_pack_bf16(row_value(slot, 0, 0), row_value(slot, 0, 1));
+            const bf16x8 A1 = mcg_pack_bf16(row_value(slot, 1, 0), row_value(slot, 1, 1));
 #pragma unroll
             for (int n = 0; n < RN; ++n) {
                 acc[0][n] = mcg_mfma_bf16(Br[slot][n], A0, acc[0][n]);
@@ -203,6 +220,21 @@ __global__ __launch_bounds__(256) void mcg_gemm_bf16_kernel(McgGemmArgs p) {
         if (kb < blocks) compute(0);
         if (kb + 1 < blocks) compute(1);
         bseg += (size_t)blocks * bstride;
+    };
+    int ra[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ra[m][q] = rA[m];
+    if (p.K1 > 0) segment(std::integral_constant<int, 1>{}, p.A1, p.K1, p.lda1, ra);
+    if (p.K2 > 0) {
+        if constexpr (GATHER >= 2) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) { const int4 sl = p.a2_rows[rA[m]]; ra[m][0] = sl.x; ra[m][1] = sl.y; ra[m][2] = sl.z; ra[m][3] = sl.w; }
+            segment(std::integral_constant<int, GATHER>{}, p.A2, p.K2, p.lda2, ra);
+        } else {
+            segment(std::integral_constant<int, 1>{}, p.A2, p.K2, p.lda2, ra);
+        }
     }
 #pragma unroll
     for (int n = 0; n < RN; ++n) {
@@ -849,9 +881,15 @@ static inline hipError_t mcg_gemm_launch(const McgGemmArgs& a, hipStream_t s, bo
         return hipGetLastError();
     }
     if (bf16) {
-        if (rn == 3) hipLaunchKernelGGL(mcg_gemm_bf16_kernel<3>, grid, dim3(256), 0, s, a);
-        else if (rn == 2) hipLaunchKernelGGL(mcg_gemm_bf16_kernel<2>, grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(mcg_gemm_bf16_kernel<1>, grid, dim3(256), 0, s, a);
+        McgGemmArgs b = a;
+        b.gemm_blocks = (int)grid.x;
+        if (a.side_x) grid.x += (unsigned)((a.side_M * 4 + 255) / 256);     // coordinate-update side job behind the GEMM's workgroups
+        const int gather = (a.a2_rows != nullptr && a.K2 > 0) ? (a.a2_nsum > 2 ? 4 : 2) : 0;
+#define MCG_GB16(RN_) do { if (gather == 4) hipLaunchKernelGGL((mcg_gemm_bf16_kernel<RN_, 4>), grid, dim3(256), 0, s, b); \
+                           else if (gather == 2) hipLaunchKernelGGL((mcg_gemm_bf16_kernel<RN_, 2>), grid, dim3(256), 0, s, b); \
+                           else hipLaunchKernelGGL((mcg_gemm_bf16_kernel<RN_, 0>), grid, dim3(256), 0, s, b); } while (0)
+        if (rn == 3) MCG_GB16(3); else if (rn == 2) MCG_GB16(2); else MCG_GB16(1);
+#undef MCG_GB16
         return hipGetLastError();
     }
     if (rn == 3) hipLaunchKernelGGL(mcg_gemm_kernel<3>, grid, dim3(256), 0, s, a);

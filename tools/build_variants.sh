@@ -9,7 +9,7 @@ OUT="$ROOT/tools/native/variants"
 mkdir -p "$OUT"
 make -C "$CS" -j4 >/dev/null          # the shared objects of the untouched sources
 VAR="mcg_edge_exact mcg_edge_bf16 mcg_egnn_api"
-REST="mcg_egnn_model.o mcg_egnn_plan.o mcg_plan_host.o mcg_sampler.o mcg_gcn.o mcg_misc.o mcg_shape.o mcg_post.o"
+REST="mcg_egnn_model.o mcg_egnn_plan.o mcg_plan_host.o mcg_sampler.o mcg_gcn.o mcg_misc.o mcg_shape.o mcg_post.o mcg_devmem.o"
 while [ $# -ge 2 ]; do
   tag="$1"; flags="$2"; shift 2
   objs=""
