@@ -53,7 +53,8 @@ def parse():
     ap.add_argument("--diffusion-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-phi-calls", type=int, default=3)
-    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the CPU baseline; 0 (default) = the best of a bounded sweep over 8 / 16 / 32 / 64 on one B/8 call")
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="also time one denoiser call at B/8 with torch.set_num_threads(os.cpu_count()) (BASELINE.md section 3's "
                          "rule; ~80 s on the 256-core GPU box, where it is 229x slower than 16 threads)")
@@ -156,7 +157,9 @@ def cpu_baseline(args, sd, gsd):
     Threads: BASELINE.md section 3 says `torch.set_num_threads(os.cpu_count())`.  On the GPU box's 256-core host
     that rule makes the aten kernels ~20x SLOWER than 16 threads (8: 0.68 s, 16: 0.40 s, 32: 0.70 s, 128: 2.7 s per
     call at B=16; one call at B=8: 0.36 s with 16 threads, 81.9 s with 256 - profiles/round2_bench_c2.json): the
-    headline baseline therefore uses the thread count that is best for the CPU (--cpu-threads, default 16);
+    headline baseline therefore uses the thread count that is best for the CPU on THIS host: the winner of a bounded sweep
+    (8 / 16 / 32 / 64 threads, one warm + one timed denoiser call at B/8 each, stopped past the knee; `thread_sweep_...` in
+    the line) unless --cpu-threads fixes it;
     --cpu-all-cores measures the os.cpu_count() rule beside it on a B/8 slice (`all_cores`), so both numbers are on
     record."""
     from ml_conformer_generator_amd.synthetic import synth_gcn_inputs
@@ -164,8 +167,6 @@ def cpu_baseline(args, sd, gsd):
     from oracle import gcn_oracle as GO
     from oracle import host_oracle as HO
     n_all = os.cpu_count() or 1
-    cores = min(n_all, args.cpu_threads)
-    torch.set_num_threads(cores)
     B, n = args.n_samples, args.n_atoms
     g = torch.Generator().manual_seed(3)
     sizes = torch.full((B,), n)
@@ -173,6 +174,26 @@ def cpu_baseline(args, sd, gsd):
     z = torch.randn(B, n, 11, generator=g) * nm
     ctx = torch.tensor([-0.99, -1.66, -1.66]).view(1, 1, 3).repeat(B, n, 1) * nm
     t = torch.full((B, 1), 0.5)
+    # thread count: the best of a bounded sweep (one denoiser call at B/8 per candidate, a few seconds in all) unless
+    # --cpu-threads fixes it - the baseline is quoted at the count that is best for the CPU on THIS host
+    sweep = None
+    if args.cpu_threads > 0:
+        cores = min(n_all, args.cpu_threads)
+    else:
+        Bs = max(1, B // 8)
+        nms, ems = HO.masks_from_sizes(sizes[:Bs], n)
+        sweep = {}
+        with torch.no_grad():
+            for cand in sorted({c for c in (8, 16, 32, 64) if c <= n_all} | ({n_all} if n_all < 8 else set())):
+                torch.set_num_threads(cand)
+                EO.egnn_dynamics(sd, t[:Bs], z[:Bs], nms, ems, ctx[:Bs])          # warm this pool size
+                t0 = time.time()
+                EO.egnn_dynamics(sd, t[:Bs], z[:Bs], nms, ems, ctx[:Bs])
+                sweep[cand] = time.time() - t0
+                if sweep[cand] > 3.0 * min(sweep.values()):
+                    break                                                         # past the knee: more threads only get slower
+        cores = min(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
     with torch.no_grad():
         t0 = time.time()
         for _ in range(args.cpu_phi_calls):
@@ -206,6 +227,7 @@ def cpu_baseline(args, sd, gsd):
     total = phi_s * calls + gcn_s
     return {"value": B / total, "unit": "molecules/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
             "host_cores": n_all,
+            "thread_sweep_s_per_call_at_B_over_8": sweep,
             "sample": f"{args.cpu_phi_calls} of {calls} denoiser calls ({phi_s:.2f} s each) + 1 GCN pass "
                       f"({gcn_s:.2f} s) at B={B}, n={n}; extrapolated x{calls}", "phi_call_s": phi_s,
             "all_cores": all_cores}
@@ -331,7 +353,7 @@ def config0_plumbing(args, gen, sd, gsd, dev, fence):
         from oracle import diffusion_oracle as DO
         from oracle import gcn_oracle as GO
         from oracle import host_oracle as HO
-        cores = min(os.cpu_count() or 1, args.cpu_threads)
+        cores = min(os.cpu_count() or 1, args.cpu_threads if args.cpu_threads > 0 else 16)
         torch.set_num_threads(cores)
         norms = {k: torch.tensor(v) for k, v in CONTEXT_NORMS.items()}
         t0 = time.time()

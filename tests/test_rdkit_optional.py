@@ -1,0 +1,45 @@
+"""Runs ONLY where RDKit is installed (it is not in the build container nor on the GPU boxes of this project): the two
+RDKit-bound modules against real RDKit.  Everything here is skipped offline; the plumbing around these modules is covered
+by tests/test_host_logic.py with stand-ins."""
+import numpy as np
+import pytest
+import torch
+
+Chem = pytest.importorskip("rdkit.Chem")
+
+
+def _ethanol():
+    z = [6, 6, 8]
+    xyz = np.array([[-0.887, 0.175, -0.013], [0.460, -0.515, -0.046], [1.443, 0.428, 0.270]], dtype=np.float64)
+    return z, xyz
+
+
+def test_rdkit_provider_returns_a_permutation_and_a_symmetric_connectivity():
+    from ml_conformer_generator_amd import rdkit_order
+    z, xyz = _ethanol()
+    order, conn = rdkit_order.rdkit_provider(z, xyz)
+    assert sorted(order) == [0, 1, 2]
+    assert conn.shape == (3, 3) and (conn == conn.T).all() and conn[0, 1] == 1 and conn[1, 2] == 1 and conn[0, 2] == 0
+    # the order is what the reference's canonicalise() applies: RenumberAtoms(mol, order) puts old atom order[p] at position p
+    mol = Chem.MolFromXYZBlock(rdkit_order.xyz_block(z, xyz))
+    from rdkit.Chem import rdDetermineBonds
+    rdDetermineBonds.DetermineConnectivity(mol)
+    Chem.MolToSmiles(mol)
+    ren = Chem.RenumberAtoms(mol, order)
+    assert [a.GetAtomicNum() for a in ren.GetAtoms()] == [z[i] for i in order]
+    with pytest.raises(ValueError):
+        rdkit_order.rdkit_provider([6, 6], np.array([[0.0, 0, 0], [9.0, 0, 0]]))          # no bond perceived: the reference raises
+
+
+def test_rdkit_finish_builds_the_mol_like_redefine_bonds():
+    from ml_conformer_generator_amd import rdkit_finish
+    from ml_conformer_generator_amd.handoff import GeneratedMolecule
+    z, xyz = _ethanol()
+    bo = torch.tensor([[0, 1, 0], [1, 0, 1], [0, 1, 0]], dtype=torch.int8)
+    rec = GeneratedMolecule(z, torch.tensor(xyz, dtype=torch.float32), bo)
+    mol = rdkit_finish.mol_from_record(rec)
+    assert mol.GetNumAtoms() == 3 and mol.GetNumBonds() == 2
+    assert not any(a.GetIsAromatic() for a in mol.GetAtoms())
+    out = rdkit_finish.finish([rec], optimise_geometry=False)
+    assert out[0] is not None and Chem.MolToSmiles(out[0]) == "CCO"
+    assert rdkit_finish.samples([rec])[0].GetNumBonds() == 0
