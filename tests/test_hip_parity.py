@@ -1763,17 +1763,27 @@ def test_new_size_vector_every_call_reuses_pooled_plan_memory(edm_sd):
 def test_bf16_mode_gathers_partial_sums_in_the_node_gemm(edm_sd):
     """configs[4] arithmetic at (half) its per-GPU size: in bf16 mode the node GEMM reads an atom's aggregate straight from
     the 64-row edge kernel's per-unit partial sums (<= 4 rows of P summed and divided by 100 in its A-loader - no combine
-    launch) and carries the coordinate update as a side job (no update launch).  Checked against the stand-alone route
-    (`mcg_egnn_gcl_debug` materialises the aggregate with the combine kernel): the aggregate the GEMM gathers is the same
-    sum in the same slot order, so ONE GCL layer must give bit-identical h; the whole call stays within the bf16 tolerance
-    of the fp32 path, on one and on two molecule ranges, at every wave-tile width."""
+    launch) and carries the coordinate update as a side job (no update launch).  Same operand rounding and the same k order
+    per output element at every wave-tile width, so
+      * the call must be BIT-IDENTICAL between the wave-tile widths (MCG_OPT_GEMM_RN; the launch counters say which ran), on
+        one and on two molecule ranges;
+      * ONE GCL layer must be bit-identical between the gathering GEMM and the stand-alone combine route
+        (`mcg_egnn_gcl_debug` materialises the aggregate);
+      * the whole call stays within the bf16 tolerance of the fp32 path."""
     import numpy as np
     from ml_conformer_generator_amd import _lib
     from ml_conformer_generator_amd.egnn import EGNNDynamics
     L = _lib.lib()
+
+    def launches():
+        c = np.zeros(32, dtype=np.int64)
+        _lib.check(L.mcg_debug_gemm_launches(c.ctypes.data, 1), "mcg_debug_gemm_launches")
+        return c.reshape(4, 8)
+
     g = torch.Generator().manual_seed(77)
-    B, N = 120, 39
+    B, N = 160, 39
     sizes = torch.randint(15, 40, (B,), generator=g)
+    assert int(sizes.sum()) >= 2 * 2048
     nm = (torch.arange(N).unsqueeze(0) < sizes.unsqueeze(1)).float().unsqueeze(2)
     z = (torch.randn(B, N, 11, generator=g) * nm).to(DEV)
     ctx = (torch.randn(B, 1, 3, generator=g).repeat(1, N, 1) * nm).to(DEV)
@@ -1788,10 +1798,15 @@ def test_bf16_mode_gathers_partial_sums_in_the_node_gemm(edm_sd):
         assert plan.edge_mt == 4
         for rn in (0, 1, 2, 3):
             _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_GEMM_RN, rn), "mcg_egnn_set_option")
+            launches()
             outs.append(d.run(plan, t, z, ctx).clone())
+            c = launches()
+            assert int(c[1].sum()) == 63 * n_ranges, c
+            if rn:
+                assert int(c[1][rn]) == 63 * n_ranges, (rn, c)
         _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_GEMM_RN, 0), "mcg_egnn_set_option")
     for k, o in enumerate(outs):
-        assert torch.equal(o, outs[4 * (k // 4)])           # tile widths do not change a bit (same k order per output element)
+        assert torch.equal(o, outs[4 * (k // 4)]), k        # kernels and tile widths do not change a bit
         # (molecule ranges cut the 64-row units elsewhere: an atom's partial sums split differently - fp32 re-association
         #  that the bf16 operand rounding can amplify to a rounding flip)
         assert float((o - outs[0]).abs().max()) <= 3e-3 * float(ref32.abs().max())
@@ -1802,8 +1817,6 @@ def test_bf16_mode_gathers_partial_sums_in_the_node_gemm(edm_sd):
     h0 = torch.randn(M, 420, generator=g).to(DEV)
     x0 = (torch.randn(M, 3, generator=g) * 2).to(DEV)
     via_combine = d.gcl_debug(plan, 0, h0, x0, x0)["h_out"]
-    count = np.zeros(32, dtype=np.int64)
-    _lib.check(L.mcg_debug_gemm_launches(count.ctypes.data, 1), "mcg_debug_gemm_launches")
     h_blk, x_blk = d.block_debug(plan, 0, h0, x0, x0)         # gcl_0, gcl_1, coordinate layer
     via2 = d.gcl_debug(plan, 1, via_combine, x0, x0)["h_out"]
     assert torch.equal(h_blk, via2)
