@@ -70,3 +70,26 @@ def test_plan_size_limit_is_reported_not_overflowed():
     h = C.c_void_p()
     rc = L.mcg_plan_create(30000, 39, n.ctypes.data_as(C.c_void_p), 0, C.byref(h))
     assert rc != 0 and b"too large" in L.mcg_last_error()
+
+
+def test_header_is_plain_c_and_argument_checks_of_the_new_entry_points(tmp_path):
+    """`include/mlconfgen_hip.h` is the drop-in boundary: it must compile as C99 and as C++ on its own (plain pointers and
+    sizes, no torch / HIP types), and the round-4 entry points refuse bad arguments without a GPU."""
+    import shutil
+    import subprocess
+    src = tmp_path / "h.c"
+    src.write_text('#include "mlconfgen_hip.h"\nint main(void) { return mcg_abi_version() == 0; }\n')
+    inc = os.path.join(REPO, "include")
+    if shutil.which("gcc"):
+        r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc, str(src)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    if shutil.which("g++"):
+        r = subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    h = _lib.lib()
+    assert h.mcg_handoff_ex(None, None, None, 4, 19, 1.3, None, None, None, None, None, None, None, None) != 0
+    assert b"mcg_handoff_ex" in h.mcg_last_error()
+    counts = (ctypes.c_int64 * 32)()
+    assert h.mcg_debug_gemm_launches(counts, 1) == 0 and all(v >= 0 for v in counts)
