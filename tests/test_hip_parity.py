@@ -1691,7 +1691,12 @@ def test_sharded_path_on_one_rank_rccl_in_a_fresh_process():
     import subprocess
     import sys
     from conftest import REPO
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29573", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "rccl_one_rank_check.py")], capture_output=True,
