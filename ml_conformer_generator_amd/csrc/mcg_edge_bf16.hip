@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
         }
     };
     // MFMAs of one ring stage: weight part `part` of block kb against activation parts 0 .. SPLIT-1-part
-    auto stage_mfma = [&](const bf16x8 (&Bc)[NS_T], int half, int part) {
+    auto stage_mfma = [&](const bf16x8 (&Bc)[NS_T], int half, int part, auto&& mid) {
         // A fragments of row tile mt+1 are fetched from LDS while the MFMAs of row tile mt run (pinned: left
         // alone hipcc hoists all 4 x SPLIT fragment reads to the top of the stage and spills)
         const int nq = SPLIT - part;
@@ -377,29 +377,47 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
                     for (int i = 0; i < NS_T; ++i) acc[mt][i] = mcg_mfma_bf16(af[mt & 1][q], Bc[i], acc[mt][i]);
                 }
             if (SPLIT > 1) __builtin_amdgcn_sched_barrier(0);
+            if (mt == 1) mid();        // (bf16: the next block's A operand is generated here, under the second half's MFMAs)
         }
     };
     // one k-block: [barrier] A-operand loads of block kb+1 | per weight part: MFMAs, then the B loads two stages
     // ahead into the fragments just consumed | A operand of block kb+1 -> LDS.  sched_barrier pins this order.
     // `first` = ring slot of the block's first stage (stages alternate slots; SPLIT = 3 flips it every block).
-    auto block = [&](int kb, int first) {
+    // bf16 (SPLIT = 1): the layer-1 inputs of block kb + 2 are requested at the top of block kb, TWO blocks (900 cycles of
+    // MFMA work) ahead of their use - one block (450 cycles) is less than an L2 round trip under load, and the A generation
+    // then waited for them (round-3 ablation: -4 % with L2-hot inputs).  With the inputs of block kb + 1 already there, its A
+    // operand is generated in the MIDDLE of block kb instead of at its end: the ds_write and the other waves' progress to the
+    // next barrier hide under the remaining 14 MFMAs.  Two register sets alternate with the unrolled block pair.
+    // Measured at the 256-ragged shape: 5.25 -> 5.12 (two-block distance) -> 5.06 ms per denoiser call (mid-block
+    // generation); a four-slot A ring with ONE barrier per two blocks on top of it was slower (5.27): profiles/round4_probes.txt.
+    // f32x6 (SPLIT = 3) keeps the one-block distance and the generation at the end of the block: its blocks are three stages
+    // long and its register file is full.
+    f32x4 vset[SPLIT == 1 ? 2 : 1][4];
+    auto block = [&](int kb, int first, auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;       // SPLIT = 1: the set that receives block kb + 2; the other holds kb + 1
         const int half = kb & 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // my A-tile writes of the previous block
         asm volatile("s_barrier" ::: "memory");                      // A(kb) visible; A ring half^1 free
         f32x4 v[4];
-        if (SPLIT == 1) { load_a(kb + 1, v); __builtin_amdgcn_sched_barrier(0); }
+        if (SPLIT == 1) { load_a(kb + 2, vset[SET]); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
         for (int part = 0; part < SPLIT; ++part) {
             const int slot = (first + part) & 1;
             // (f32x6: the next block's operand inputs are requested behind the first, register-hungriest stage -
             //  still 84 MFMAs ahead of their use)
             if (SPLIT > 1 && part == 1) { load_a(kb + 1, v); __builtin_amdgcn_sched_barrier(0); }
-            stage_mfma(Bq[slot], half, part);
+            stage_mfma(Bq[slot], half, part, [&] {
+                if (SPLIT == 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    agen_store(vset[(SET ^ 1) & (SPLIT == 1 ? 1 : 0)], kb + 1 < KB16 ? kb + 1 : KB16 - 1, half ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
             __builtin_amdgcn_sched_barrier(0);
             load_b(Bq[slot], kb * SPLIT + part + 2);
             __builtin_amdgcn_sched_barrier(0);
         }
-        agen_store(v, kb + 1 < KB16 ? kb + 1 : KB16 - 1, half ^ 1);
+        if (SPLIT != 1) agen_store(v, kb + 1 < KB16 ? kb + 1 : KB16 - 1, half ^ 1);
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -409,12 +427,13 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
     {
         f32x4 v[4];
         load_a(0, v);
+        if (SPLIT == 1) load_a(1, vset[SPLIT == 1 ? 1 : 0]);      // block 1 -> set 1 (consumed in the middle of block 0)
         agen_store(v, 0, 0);
     }
 #pragma unroll 1
     for (int kb = 0; kb < KB16; kb += 2) {        // KB16 = 14 is even
-        block(kb, 0);
-        block(kb + 1, SPLIT & 1);                 // an odd number of stages per block flips the ring phase
+        block(kb, 0, std::integral_constant<int, 0>{});
+        block(kb + 1, SPLIT & 1, std::integral_constant<int, SPLIT == 1 ? 1 : 0>{});     // an odd number of stages per block flips the ring phase
     }
 
     // ---- epilogue
