@@ -380,6 +380,25 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
             if (mt == 1) mid();        // (bf16: the next block's A operand is generated here, under the second half's MFMAs)
         }
     };
+    // bf16 (SPLIT = 1) walks the stage COLUMN tile by column tile: all four A fragments are read up front (16 VGPRs), column
+    // tile i's weight fragment meets them in four MFMAs and is then dead, so its refill for two stages ahead is issued right
+    // behind them - the weight stream is requested progressively through the block instead of in one burst after it.
+    auto stage_mfma_cols = [&](bf16x8 (&Bc)[NS_T], int half, int next_stage, auto&& mid) {
+        bf16x8 af[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) af[mt] = a_lds[(half * 4 + mt) * 64 + lane];
+        const int st = next_stage < NSTAGE ? next_stage : NSTAGE - 1;
+        const int base = st * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < NS_T; ++i) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt][i] = mcg_mfma_bf16(af[mt], Bc[i], acc[mt][i]);
+            __builtin_amdgcn_sched_barrier(0);
+            Bc[i] = __builtin_bit_cast(bf16x8, i < NS_T - 1 ? ld16(rs_b, ov, base + i * 4 * 64 * 16) : ld16(rs_b, ov6, base));
+            __builtin_amdgcn_sched_barrier(0);
+            if (i == 3) mid();          // (position 0 / 1 / 3 / 5 measured: no difference)
+        }
+    };
     // one k-block: [barrier] A-operand loads of block kb+1 | per weight part: MFMAs, then the B loads two stages
     // ahead into the fragments just consumed | A operand of block kb+1 -> LDS.  sched_barrier pins this order.
     // `first` = ring slot of the block's first stage (stages alternate slots; SPLIT = 3 flips it every block).
@@ -406,15 +425,17 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
             // (f32x6: the next block's operand inputs are requested behind the first, register-hungriest stage -
             //  still 84 MFMAs ahead of their use)
             if (SPLIT > 1 && part == 1) { load_a(kb + 1, v); __builtin_amdgcn_sched_barrier(0); }
-            stage_mfma(Bq[slot], half, part, [&] {
-                if (SPLIT == 1) {
+            if constexpr (SPLIT == 1) {
+                stage_mfma_cols(Bq[slot], half, kb + 2, [&] {
                     __builtin_amdgcn_sched_barrier(0);
                     agen_store(vset[(SET ^ 1) & (SPLIT == 1 ? 1 : 0)], kb + 1 < KB16 ? kb + 1 : KB16 - 1, half ^ 1);
                     __builtin_amdgcn_sched_barrier(0);
-                }
-            });
-            __builtin_amdgcn_sched_barrier(0);
-            load_b(Bq[slot], kb * SPLIT + part + 2);
+                });
+            } else {
+                stage_mfma(Bq[slot], half, part, [] {});
+                __builtin_amdgcn_sched_barrier(0);
+                load_b(Bq[slot], kb * SPLIT + part + 2);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (SPLIT != 1) agen_store(v, kb + 1 < KB16 ? kb + 1 : KB16 - 1, half ^ 1);
