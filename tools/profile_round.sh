@@ -28,7 +28,7 @@ f=$(find $O/pmc_c3_bf16_mfma -name "*counter_collection.csv" | head -1); [ -n "$
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3_bf16 -- python3 $R/tools/bench_kernels.py --shape c3 --dtype bf16 --ranges 1 > $O/prof_c3_bf16.log 2>&1
 f=$(find $O/prof_c3_bf16 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/c3_bf16_kernel_stats.csv
 timeout 400 python3 $R/bench.py --n-samples 256 --variance 12 --no-cpu-baseline --no-x6-probe > $O/bench_c3.json 2>/dev/null
-timeout 400 python3 $R/bench.py --fragment --dtype bf16 --n-samples 256 --variance 12 --diffusion-steps 250 --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_c5_share.json 2>/dev/null
+timeout 400 python3 $R/bench.py --fragment --dtype bf16 --n-samples 256 --variance 12 --diffusion-steps 250 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_c5_share.json 2>/dev/null
 # multi-GPU code paths on the one GPU there is: the real RCCL collectives on a 1-rank group, and the 2-rank control flow over gloo
 MCG_FORCE_COLLECTIVE=1 timeout 300 python3 $R/bench.py --no-cpu-baseline --no-x6-probe --no-config2 --no-config0 --no-config4 > $O/bench_rccl_1rank.json 2> $O/bench_rccl_1rank.err
 MCG_DIST_BACKEND=gloo MCG_BENCH_TIMEOUT=500 timeout 600 python3 $R/bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_2rank_gloo_dryrun_one_gpu.json 2> $O/bench_2rank_gloo.err
