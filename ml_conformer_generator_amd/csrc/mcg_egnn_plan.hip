@@ -118,14 +118,15 @@ extern "C" {
 
 void mcg_plan_destroy(mcg_plan* p) {
     if (!p) return;
+    // the blocks go back to the plan pool, not to the driver: nothing may still be running on them when another plan can
+    // take them (hipFree used to wait implicitly).  Once, up front, before the molecule ranges hand back theirs.
+    if (!p->is_sub && !p->allocs.empty()) (void)hipDeviceSynchronize();
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     for (mcg_plan* q : p->subs) mcg_plan_destroy(q);
     for (hipStream_t st : p->streams) (void)hipStreamDestroy(st);
     for (hipEvent_t e : p->ev_join) (void)hipEventDestroy(e);
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
-    // the blocks go back to the plan pool, not to the driver: nothing may still be running on them (hipFree used to wait)
-    if (!p->allocs.empty() && !p->is_sub) (void)hipDeviceSynchronize();
     for (void* q : p->allocs) mcg_dev_free(q);
     delete p;
 }
