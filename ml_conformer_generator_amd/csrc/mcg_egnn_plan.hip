@@ -102,7 +102,8 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, const m
     void* ws_block = nullptr;
     if (int e = mcg_dev_alloc(ws_bytes, &ws_block)) { mcg_plan_destroy(p); return e; }
     p->allocs.push_back(ws_block);
-    if (hipMemset(ws_block, 0, ws_bytes) != hipSuccess) {           // (synchronous: the plan's streams do not order with stream 0)
+    // (the plan's own streams are non-blocking, i.e. they do not order with stream 0: wait for the memset here)
+    if (hipMemset(ws_block, 0, ws_bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
         (void)hipGetLastError();
         mcg_set_error("mcg_plan_create: workspace memset failed");
         mcg_plan_destroy(p);
