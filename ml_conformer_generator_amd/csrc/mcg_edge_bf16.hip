@@ -415,10 +415,11 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
     auto block = [&](int kb, int first, auto set_tag) {
         constexpr int SET = decltype(set_tag)::value;       // SPLIT = 1: the set that receives block kb + 2; the other holds kb + 1
         const int half = kb & 1;
+        // (bf16: the request for block kb + 2 goes out BEFORE the rendezvous - it depends on nothing the barrier orders)
+        if (SPLIT == 1) { load_a(kb + 2, vset[SET]); __builtin_amdgcn_sched_barrier(0); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // my A-tile writes of the previous block
         asm volatile("s_barrier" ::: "memory");                      // A(kb) visible; A ring half^1 free
         f32x4 v[4];
-        if (SPLIT == 1) { load_a(kb + 2, vset[SET]); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
         for (int part = 0; part < SPLIT; ++part) {
             const int slot = (first + part) & 1;
