@@ -1,15 +1,16 @@
-"""EDM -> GCN hand-off and bond write-back without RDKit.
+"""EDM -> GCN hand-off and bond write-back on the device.
 
 The reference goes through RDKit here (`samples_to_rdkit_mol`, `canonicalise`,
 `prepare_adj_mat_seer_input`, `redefine_bonds`, `standardize_mol`;
-mol_utils.py:18-57,110-223, standardizer.py).  RDKit's connectivity perception and
-canonical atom order cannot be reproduced bit-for-bit, so this native route is a
-documented substitute (parity unpinned at the RDKit boundary): atoms keep their
-generation order, 1-order connectivity comes from a covalent-radius rule, and
-"valid" is a valence/connectivity proxy.  The tensor halves (decode, distances + I,
-pad 42, lower-triangle bond write-back) follow the reference and are checked against
-`oracle/host_oracle.py`.  All of it runs in two HIP launches (`mcg_handoff`,
-`mcg_bond_writeback`); one D2H copy at the end.
+mol_utils.py:18-57,110-223, standardizer.py).  The tensor halves (atom decode, distances + I,
+connectivity + I, pad 42, lower-triangle bond write-back) run in two HIP launches
+(`mcg_handoff_ex`, `mcg_bond_writeback`), follow the reference and are checked against
+`oracle/host_oracle.py` and reference-generated fixtures; one D2H copy at the end.
+The two decisions RDKit OWNS in front of the GCN - the canonical-SMILES atom order and the
+1-order connectivity (`canonicalise`, mol_utils.py:110-126) - are INPUTS of the hand-off launch
+(`order`, `connectivity`): RDKit's own where RDKit imports (`rdkit_order.py`), a caller's, or -
+when neither is given - the labelled substitutes (generation order, covalent-radius rule:
+parity unpinned against RDKit).  "valid" without RDKit is a valence / connectivity proxy.
 """
 from __future__ import annotations
 
