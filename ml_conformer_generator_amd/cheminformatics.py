@@ -204,3 +204,47 @@ def evaluate_shape(reference_coord: torch.Tensor, sample_coords: torch.Tensor, n
     results = [{"coords": aligned_c[b, : int(nn_c[b])].clone(), "shape_tanimoto": float(best_c[b]),
                 "orientation": int(which_c[b])} for b in range(B)]
     return ref_pf, results
+
+
+def evaluate_samples(reference, samples, generator=None, device=None):
+    """`evaluate_samples` of the reference (cheminformatics/pipeline.py:17-96) with its signature and return value:
+    (mol block of the reference in its principal shape frame, per sample {"mol_block", "shape_tanimoto",
+    "chemical_tanimoto"}).  The shape half - principal frames and the four-orientation Gaussian-volume Tanimoto search - runs on
+    the HIP path for all samples at once (`evaluate_shape`); the chemical half (Morgan fingerprints radius 2, 2 048 bits, bond
+    types on, chirality off, `TanimotoSimilarity`) and the mol-block output are RDKit's own and run ONLY where RDKit imports -
+    this wrapper is untested offline (RDKit is absent from the build container and the GPU boxes;
+    `tests/test_rdkit_optional.py` runs it where RDKit and a GPU exist)."""
+    from rdkit import Chem
+    from rdkit.Chem import rdFingerprintGenerator
+    from rdkit.DataStructs.cDataStructs import TanimotoSimilarity
+    from rdkit.Geometry import Point3D
+
+    if generator is None:                                                       # pipeline.py:11-14
+        generator = rdFingerprintGenerator.GetMorganGenerator(radius=2, fpSize=2048, includeChirality=False, useBondTypes=True)
+
+    def set_positions(mol, coord):                                              # pipeline.py:99-105
+        conf = mol.GetConformer()
+        for i, point in enumerate(coord.tolist()):
+            conf.SetAtomPosition(i, Point3D(point[0], point[1], point[2]))
+        return mol
+
+    reference = Chem.RemoveHs(reference)                                        # :32
+    fp_ref = generator.GetFingerprint(reference)
+    ref_coord = torch.tensor(reference.GetConformer().GetPositions(), dtype=torch.float32)
+    stripped = [Chem.RemoveHs(s) for s in samples]                              # :61
+    if not stripped:
+        _, ref_pf = shape_quadrupole_batch((ref_coord - ref_coord.mean(0)).unsqueeze(0), torch.tensor([ref_coord.shape[0]]),
+                                           torch.device(device if device is not None else "cuda:0"))
+        return Chem.MolToMolBlock(set_positions(reference, ref_pf[0].cpu())), []
+    n_nodes = torch.tensor([m.GetNumAtoms() for m in stripped])
+    coords = torch.zeros(len(stripped), int(n_nodes.max()), 3)
+    for b, m in enumerate(stripped):
+        coords[b, : m.GetNumAtoms()] = torch.tensor(m.GetConformer().GetPositions(), dtype=torch.float32)
+    ref_pf, shape = evaluate_shape(ref_coord, coords, n_nodes, device)
+    ref_mol_block = Chem.MolToMolBlock(set_positions(reference, ref_pf))        # :44-45
+    results = []
+    for m, r in zip(stripped, shape):
+        results.append({"mol_block": Chem.MolToMolBlock(set_positions(m, r["coords"])),
+                        "shape_tanimoto": r["shape_tanimoto"],
+                        "chemical_tanimoto": TanimotoSimilarity(fp_ref, generator.GetFingerprint(m))})
+    return ref_mol_block, results

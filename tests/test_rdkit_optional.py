@@ -43,3 +43,17 @@ def test_rdkit_finish_builds_the_mol_like_redefine_bonds():
     out = rdkit_finish.finish([rec], optimise_geometry=False)
     assert out[0] is not None and Chem.MolToSmiles(out[0]) == "CCO"
     assert rdkit_finish.samples([rec])[0].GetNumBonds() == 0
+
+
+@pytest.mark.gpu
+def test_evaluate_samples_wrapper_runs_where_rdkit_and_a_gpu_exist():
+    from ml_conformer_generator_amd.cheminformatics import evaluate_samples
+    from rdkit.Chem import AllChem
+    ref = Chem.AddHs(Chem.MolFromSmiles("CCOC(=O)c1ccccc1"))
+    AllChem.EmbedMolecule(ref, randomSeed=1)
+    other = Chem.AddHs(Chem.MolFromSmiles("CCOC(=O)c1ccccn1"))
+    AllChem.EmbedMolecule(other, randomSeed=2)
+    block, res = evaluate_samples(ref, [ref, other])
+    assert "V2000" in block and len(res) == 2
+    assert abs(res[0]["chemical_tanimoto"] - 1.0) < 1e-9 and res[0]["shape_tanimoto"] > 0.99
+    assert 0.0 < res[1]["chemical_tanimoto"] < 1.0 and 0.0 < res[1]["shape_tanimoto"] <= 1.0
