@@ -651,6 +651,7 @@ def main():
 
     elapsed, sampler_ms, finite, valid_frac = timed_passes(gen, ctx, B * world, args.n_atoms, args.variance, frag_kw,
                                                            args.steps, args.warmup, fence)
+    head_assembly_ms = gen.last_host_assembly_ms          # D2H of the (gathered) result tensors + molecule records, last pass
     if use_dist:
         tt = torch.tensor([elapsed, 0.0 if finite else 1.0], dtype=torch.float64,
                           device=dev if dist.get_backend() == "nccl" else torch.device("cpu"))
@@ -735,6 +736,7 @@ def main():
             "valid_proxy_fraction": valid_frac,
             "value_x_reference_valid_fraction": value * 0.48,
             "egnn_step_ms_per_batch": egnn_step_ms,
+            "host_assembly_ms": head_assembly_ms,
             "outputs_finite": finite,
             "roofline": roof,
             "aggregate_roofline": {"kernel": "k_aggregate (stand-alone gate*mask*segment-sum probe)", "bound": "hbm",

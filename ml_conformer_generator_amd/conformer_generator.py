@@ -301,6 +301,8 @@ class MLConformerGenerator(torch.nn.Module):
         _, res = mcg_dist.sharded_generate(
             n_samples, lambda: mcg_dist.draw_global_sizes(n_samples, lo_n, hi_n, group), run_shard, group=group,
             seed=seed, seed_fn=seed_device, gather_dst=0 if gather == "rank0" else None)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)       # (the D2H copies below would wait for the device anyway: keep that out of the figure)
         t0 = time.perf_counter()
         mols = molecules_from_tensors(res["x"], res["elements"], res["bond"], res["n_nodes"], res["valid"])
         self.last_host_assembly_ms = (time.perf_counter() - t0) * 1e3      # D2H of the gathered tensors + record views
