@@ -495,6 +495,59 @@ def edge_roofline(args, gen, dev, dtype, traffic=None, traffic_source=None):
                   "flops_per_launch": fl}
 
 
+def host_stage_report(gen):
+    """The two RDKit-owned host stages around the GCN (canonical order + connectivity before it, `redefine_bonds` +
+    `standardize_mol` / MMFF behind it; `host_pool.py`).  Where RDKit imports they run inside the timed region, fanned out
+    over `n_host_workers` worker processes, and their wall times are reported; RDKit exists on none of this project's
+    boxes, so there the object carries a labelled PROBE instead: the same pipeline (`rdkit_order.OrderStage` ->
+    per-group 'launch' -> `rdkit_finish.FinishStage`) over 256 molecules with a fake 2 ms-per-molecule function in each
+    stage (tests/fake_host_tasks.py), pooled against serial, warm."""
+    from ml_conformer_generator_amd import host_pool as HP
+    from ml_conformer_generator_amd import rdkit_finish as RF
+    from ml_conformer_generator_amd import rdkit_order as RO
+    from ml_conformer_generator_amd.conformer_generator import HAVE_RDKIT
+    from ml_conformer_generator_amd.handoff import molecules_from_tensors
+    out = {"rdkit": HAVE_RDKIT, "n_host_workers": gen.n_host_workers,
+           "host_order_ms": gen.last_host_order_ms, "host_finish_ms": gen.last_host_finish_ms}
+    fake = os.path.join(REPO, "tests", "fake_host_tasks.py")
+    if HAVE_RDKIT or not os.path.exists(fake):
+        return out
+    try:
+        B, N = 256, 27
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(B, N, 3, generator=g) * 1.7
+        h = torch.nn.functional.one_hot(torch.randint(0, 7, (B, N), generator=g), 8).float()
+        n = torch.full((B,), N)
+        recs = molecules_from_tensors(x, torch.full((B, 42), 6, dtype=torch.int8),
+                                      torch.randint(0, 3, (B, 42, 42), generator=g).to(torch.int8), n.to(torch.int32),
+                                      torch.ones(B, dtype=torch.uint8))
+        groups = RO.launch_groups(B)
+
+        def run(ex):
+            t0 = time.perf_counter()
+            st = RO.OrderStage(HP.TaskRef(fake, "order_chunk"), x, h, n, ex, groups)
+            fin = RF.FinishStage(HP.TaskRef(fake, "finish_chunk"), True, ex)
+            for gi, (lo, hi) in enumerate(groups):
+                st.result(gi)
+                fin.add(recs[lo:hi])
+            fin.results()
+            return (time.perf_counter() - t0) * 1e3
+        pool = HP.shared_pool(gen.n_host_workers)
+        t0 = time.perf_counter()
+        run(pool)
+        cold = (time.perf_counter() - t0) * 1e3
+        pooled = min(run(pool) for _ in range(3))
+        serial = run(HP.SerialExecutor())
+        out["probe_fake_2ms_per_molecule"] = {
+            "what": "NOT RDKit (absent here): 256 molecules through the order -> launch -> finish pipeline with a fake 2 ms-per-"
+                    "molecule function in each stage, worker processes vs the reference's one-molecule-at-a-time loop",
+            "serial_ms": serial, "pooled_ms": pooled, "speedup": serial / pooled, "workers": gen.n_host_workers,
+            "first_use_ms_incl_worker_start": cold}
+    except Exception as e:  # noqa: BLE001 - a probe must not take the bench line down
+        out["probe_error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
 def count_gpus_without_hip():
     """GPUs of this box WITHOUT any HIP / HSA call: KFD topology nodes with SIMDs (CPU nodes have simd_count 0),
     narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set.  Returns None when sysfs has no KFD topology."""
@@ -591,6 +644,11 @@ def main():
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}\n")
         sys.exit(2)
     use_dist = world > 1 or bool(os.environ.get("MCG_FORCE_COLLECTIVE"))
+    # N rank processes share one host: without a cap each keeps torch's default intra-op pool of EVERY core (256 threads per
+    # rank on the GPU box; the CPU thread sweep below shows what oversubscription costs).  The hot path needs the host for
+    # launches, the size draw and the record assembly only.
+    host_threads = max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
+    torch.set_num_threads(host_threads)
     backend = os.environ.get("MCG_DIST_BACKEND", "nccl")
     if world > 1 and backend == "nccl" and torch.cuda.device_count() < world:
         sys.stderr.write(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s)\n")
@@ -737,6 +795,8 @@ def main():
             "value_x_reference_valid_fraction": value * 0.48,
             "egnn_step_ms_per_batch": egnn_step_ms,
             "host_assembly_ms": head_assembly_ms,
+            "host_threads_per_rank": host_threads,
+            "host_stages": host_stage_report(gen),
             "outputs_finite": finite,
             "roofline": roof,
             "aggregate_roofline": {"kernel": "k_aggregate (stand-alone gate*mask*segment-sum probe)", "bound": "hbm",

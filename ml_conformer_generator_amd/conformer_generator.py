@@ -18,11 +18,16 @@ forced by the scope of this build:
     absent here); without RDKit it returns `GeneratedMolecule` records filtered by the labelled
     valence / single-fragment PROXY, and `optimise_geometry=True` cannot be honoured (one
     warning per process).  An RDKit Mol is accepted as reference conformer / fixed fragment;
+  * `n_host_workers` (default min(32, host cores); 0 = serial): the two RDKit stages - canonical order + connectivity
+    before the GCN, `redefine_bonds` + `standardize_mol` (MMFF) behind it - are fanned out over a pool of fresh worker
+    processes (`host_pool.py`) and pipelined against the GPU per group of molecules; the reference runs them one molecule
+    at a time on the calling thread (conformer_generator.py:343-366).  Same per-molecule code, same results, same order;
   * `generate_conformers_sharded(...)`: the same call, batch-sharded over the ranks of an
     initialised `torch.distributed` group (one process per GPU, one gather at the end).
 """
 from __future__ import annotations
 
+import os
 import time
 import warnings
 from typing import List, Optional, Union
@@ -36,6 +41,7 @@ from .config import (ATOM_DECODER, CONTEXT_NORMS, DIMENSION, MAX_N_NODES, MIN_N_
 from .egnn import EGNNDynamics
 from .equivariant_diffusion import EquivariantDiffusion, PredefinedNoiseSchedule
 from . import distributed as mcg_dist
+from . import host_pool
 from . import rdkit_order
 from .handoff import (GeneratedMolecule, assemble_molecules, bond_writeback_hip, molecules_from_tensors,
                       prepare_adj_mat_seer_input_hip)
@@ -54,11 +60,12 @@ except Exception:  # noqa: BLE001
 _WARNED_NO_MMFF = [False]
 
 
-def _finish(mols: List, optimise_geometry: bool):
-    """(returned list, valid fraction): the reference's RDKit gate where RDKit exists, else the proxy filter."""
+def _finish(mols: List, optimise_geometry: bool, use_rdkit: Optional[bool] = None):
+    """(returned list, valid fraction): the reference's RDKit gate where RDKit exists (serial form; the generator's own
+    route is the staged, pooled `rdkit_finish.FinishStage`), else the proxy filter."""
     if not mols:
         return [], 0.0
-    if HAVE_RDKIT:
+    if HAVE_RDKIT if use_rdkit is None else use_rdkit:
         from . import rdkit_finish
         done = rdkit_finish.finish(mols, optimise_geometry)
         kept = [m for m in done if m is not None]
@@ -85,7 +92,8 @@ class MLConformerGenerator(torch.nn.Module):
                  context_norms: dict = CONTEXT_NORMS, atom_decoder: dict = ATOM_DECODER,
                  edm_weights: Union[str, dict] = "./edm_moi_chembl_15_39.pt",
                  adj_mat_seer_weights: Union[str, dict] = "./adj_mat_seer_chembl_15_39.pt",
-                 compute_dtype: str = "f32", atom_order_provider="auto"):
+                 compute_dtype: str = "f32", atom_order_provider="auto", n_host_workers: Optional[int] = None,
+                 finisher="auto"):
         super().__init__()
         _lib.lib()       # fail loudly if the HIP library is not built
         device = torch.device("cuda:0" if device is None else device)
@@ -113,6 +121,14 @@ class MLConformerGenerator(torch.nn.Module):
         self.adj_mat_seer = adj_mat_seer
         # (atomic_numbers, coords[n,3]) -> (order, connectivity) | None per molecule: see rdkit_order.py
         self.atom_order_provider = rdkit_order.default_provider() if atom_order_provider == "auto" else atom_order_provider
+        # RDKit finish behind the GCN (`redefine_bonds` + `standardize_mol`): "auto" = RDKit's where RDKit imports, else None
+        # (the labelled proxy filter); a `host_pool.TaskRef` = the caller's chunk function; None = the proxy filter
+        self.finisher = ("rdkit" if HAVE_RDKIT else None) if finisher == "auto" else finisher
+        # host fan-out of the two RDKit stages (host_pool.py): worker PROCESSES, created at first use; 0 = this thread
+        self.n_host_workers = host_pool.default_workers() if n_host_workers is None else int(n_host_workers)
+        self._finish_stage = None    # rdkit_finish.FinishStage of the shard generated last (consumed by the callers)
+        self.last_host_order_ms = None    # wall time from the first order task to the last group's hand-off launch
+        self.last_host_finish_ms = None   # wall time spent waiting for finish results after the last group was submitted
         self.last_batch = None       # tensors of the most recent generation (x, h, n_nodes, bond)
         self.last_order = None
         self.last_valid_fraction = None   # share of the last batch that passed the validity proxy
@@ -189,7 +205,7 @@ class MLConformerGenerator(torch.nn.Module):
             m.valid = True          # no bonds yet: the connectivity proxy does not apply
         if HAVE_RDKIT:
             from . import rdkit_finish
-            return rdkit_finish.samples(mols)
+            return rdkit_finish.samples(mols, self._executor())
         return mols
 
     # ------------------------------------------------------------------ full pipeline
@@ -214,14 +230,28 @@ class MLConformerGenerator(torch.nn.Module):
         raise ValueError(
             "Either a reference RDkit Mol object or context as torch.Tensor should be provided for generation.")
 
+    def _executor(self):
+        """Where the poolable host tasks run: the process-wide `HostPool` with `n_host_workers` workers (created at the
+        first submit), or this thread."""
+        return host_pool.shared_pool(self.n_host_workers)
+
     def _generate_shard(self, ref_context, ref_n_atoms: int, variance: int, sizes: Optional[torch.Tensor],
                         n_samples: int, resample_steps, fixed_fragment, inertial_fragment_matching, blend_power,
-                        ifm_diffusion_level):
+                        ifm_diffusion_level, optimise_geometry: bool = True):
         """Sampler -> hand-off -> GCN -> bond write-back + validity proxy for `n_samples` molecules on THIS device.
-        Returns per-sample DEVICE tensors (dim 0 = n_samples; n_samples may be 0 for an empty shard)."""
+        Returns per-sample DEVICE tensors (dim 0 = n_samples; n_samples may be 0 for an empty shard).
+
+        With an atom-order provider and / or a finisher (RDKit's where RDKit imports) the part behind the sampler is a
+        pipeline over groups of molecules (conformer_generator.py:343-366 runs it one molecule at a time): every order
+        task of the batch is submitted to the host pool as soon as x, h are on the host; the hand-off + GCN + write-back
+        of group g is launched when ITS order results are in; its records are copied back and its finish tasks submitted
+        while the pool still works on the order of the later groups.  `self._finish_stage` then holds the pending finish
+        (consumed by `generate_conformers*`)."""
         N = min(ref_n_atoms + variance, self.max_n_nodes)
         D = self.dimension
         dev = self.device
+        self._finish_stage = None
+        self.last_host_order_ms = self.last_host_finish_ms = None
         if n_samples == 0:
             return dict(x=torch.zeros(0, N, 3, device=dev), elements=torch.zeros(0, D, dtype=torch.int8, device=dev),
                         bond=torch.zeros(0, D, D, dtype=torch.int8, device=dev),
@@ -233,20 +263,51 @@ class MLConformerGenerator(torch.nn.Module):
             inertial_fragment_matching=inertial_fragment_matching, blend_power=blend_power,
             ifm_diffusion_level=ifm_diffusion_level, sizes=sizes)
         n_nodes = node_mask.sum(1).reshape(-1).to(torch.long)
-        order = conn = built = None
-        if self.atom_order_provider is not None:          # host: RDKit's (or the caller's) order + connectivity
-            order, conn, built = rdkit_order.batch_order_and_connectivity(self.atom_order_provider, x, h, n_nodes)
-        # atoms, distances, connectivity AND coordinates come out in the order the GCN sees (canonicalised_samples)
-        el, dm, am, x_out = prepare_adj_mat_seer_input_hip(x, h, n_nodes, D, order=order, connectivity=conn,
-                                                           with_coords=True)
-        bond = self.adj_mat_seer.bond_orders(el, dm, am)
-        sym, valid = bond_writeback_hip(bond, el, n_nodes)
-        if built is not None and not all(built):          # `MolFromXYZBlock` returned None: the reference drops it
-            valid = valid & torch.tensor(built, dtype=torch.bool, device=valid.device)
+        provider, finisher = self.atom_order_provider, getattr(self, "finisher", None)
+        staged = provider is not None or finisher is not None
+        groups = rdkit_order.launch_groups(n_samples) if staged else [(0, n_samples)]
+        executor = self._executor() if staged else None
+        t0 = time.perf_counter()
+        # host: RDKit's (or the caller's) order + connectivity - every task of the batch goes out now
+        stage = rdkit_order.OrderStage(provider, x, h, n_nodes, executor, groups) if provider is not None else None
+        fin = None
+        if finisher is not None:
+            from . import rdkit_finish
+            fin = rdkit_finish.FinishStage(finisher, optimise_geometry, executor)
+        parts, orders = [], []
+        for g, (lo, hi) in enumerate(groups):
+            order = conn = built = None
+            if stage is not None:
+                order, conn, built = stage.result(g)
+            ng = n_nodes[lo:hi]
+            # atoms, distances, connectivity AND coordinates come out in the order the GCN sees (canonicalised_samples)
+            el, dm, am, x_out = prepare_adj_mat_seer_input_hip(x[lo:hi], h[lo:hi], ng, D, order=order, connectivity=conn,
+                                                               with_coords=True)
+            bond = self.adj_mat_seer.bond_orders(el, dm, am)
+            sym, valid = bond_writeback_hip(bond, el, ng)
+            if built is not None and not all(built):          # `MolFromXYZBlock` returned None: the reference drops it
+                valid = valid & torch.tensor(built, dtype=torch.bool, device=valid.device)
+            parts.append((x_out, el, bond, sym, valid))
+            orders.append(order if order is not None else [None] * (hi - lo))
+            if fin is not None:                               # this group's records -> the pool, behind the order tasks
+                fin.add(molecules_from_tensors(x_out, el.to(torch.int8), sym, ng.to(torch.int32), valid.to(torch.uint8)))
+        if stage is not None:
+            self.last_host_order_ms = (time.perf_counter() - t0) * 1e3
+        cat = (lambda k: parts[0][k]) if len(parts) == 1 else (lambda k: torch.cat([p[k] for p in parts], dim=0))
+        x_out, el, bond, sym, valid = (cat(k) for k in range(5))
+        self._finish_stage = fin
         self.last_batch = dict(x=x, h=h, n_nodes=n_nodes, elements=el, bond=bond, x_ordered=x_out)     # tensors only
-        self.last_order = order           # per-molecule atom orders the provider chose (None: generation order)
+        flat = [o for grp in orders for o in grp]
+        self.last_order = None if all(o is None for o in flat) else flat    # per-molecule atom orders (None: generation order)
         return dict(x=x_out, elements=el.to(torch.int8), bond=sym, n_nodes=n_nodes.to(torch.int32),
                     valid=valid.to(torch.uint8))
+
+    def _collect_finish(self, stage):
+        """The pending finish of the shard generated last -> per-sample results (None = dropped)."""
+        t0 = time.perf_counter()
+        done = stage.results()
+        self.last_host_finish_ms = (time.perf_counter() - t0) * 1e3
+        return done
 
     @torch.no_grad()
     def generate_conformers(self, reference_conformer=None, n_samples: int = 10, variance: int = 2,
@@ -260,9 +321,15 @@ class MLConformerGenerator(torch.nn.Module):
         records that pass the labelled valence / single-fragment proxy of `mcg_bond_writeback` (no MMFF: warned once)."""
         ref_context, ref_n_atoms = self._reference_context(reference_conformer, reference_context, n_atoms)
         res = self._generate_shard(ref_context, ref_n_atoms, variance, None, n_samples, resample_steps, fixed_fragment,
-                                   inertial_fragment_matching, blend_power, ifm_diffusion_level)
+                                   inertial_fragment_matching, blend_power, ifm_diffusion_level, optimise_geometry)
+        stage, self._finish_stage = getattr(self, "_finish_stage", None), None
+        if stage is not None:                     # finished per group while the later groups were still on their way
+            done = self._collect_finish(stage)
+            kept = [m for m in done if m is not None]
+            self.last_valid_fraction = len(kept) / len(done) if done else 0.0
+            return kept
         mols = molecules_from_tensors(res["x"], res["elements"], res["bond"], res["n_nodes"], res["valid"])   # single D2H
-        kept, self.last_valid_fraction = _finish(mols, optimise_geometry)
+        kept, self.last_valid_fraction = _finish(mols, optimise_geometry, use_rdkit=False)    # no finisher: the proxy
         return kept
 
     @torch.no_grad()
@@ -271,26 +338,30 @@ class MLConformerGenerator(torch.nn.Module):
                                     optimise_geometry: bool = True, resample_steps: int = 0, fixed_fragment=None,
                                     inertial_fragment_matching: bool = True, blend_power: int = 3,
                                     ifm_diffusion_level: int = 50, group=None, seed: Optional[int] = None,
-                                    gather: str = "all") -> List:
+                                    gather: str = "all", balance: str = "cost") -> List:
         """`generate_conformers` for `n_samples` molecules in TOTAL, sharded over the ranks of the initialised
         `torch.distributed` group (one process per GPU, each with its own generator instance / weight replica;
-        SURVEY.md section 8e).  The global size vector is drawn once on rank 0 and broadcast, rank r generates
-        the contiguous slice `shard_range(n_samples, r, world)`, and ONE all-gather of the result tensors at the
-        end gives every rank the full batch, in sample order.  `seed`: per-rank noise seed `seed + rank` for the
+        SURVEY.md section 8e).  The global size vector is drawn once on rank 0 and broadcast; every rank derives the same
+        assignment of molecules to ranks from it (`distributed.assign_shards`: `balance="cost"` = longest-processing-time
+        on the edge count n(n-1), "count" = contiguous equal-count slices) and generates its own; ONE all-gather of the
+        result tensors at the end gives every rank the full batch, in SAMPLE order.  `seed`: per-rank noise seed `seed + rank` for the
         device generator; None (default) = a base seed drawn on rank 0 and broadcast, so that ranks NEVER share a noise
         stream (every process starts its device generator from the same constant).  A rank whose shard fails makes
         every rank raise `distributed.ShardError`.  `gather="rank0"`: only rank 0 of the group receives (and returns) the
         whole batch - one `gather` instead of the all-gather - and every other rank returns its own shard's molecules.
-        Without an initialised group this is `generate_conformers`."""
+        Where a finisher runs (RDKit's), every rank finishes ITS OWN shard in its own host pool and the finished Mols are
+        gathered as objects.  Without an initialised group this is `generate_conformers`."""
         if gather not in ("all", "rank0"):
             raise ValueError("gather must be 'all' or 'rank0'")
         ref_context, ref_n_atoms = self._reference_context(reference_conformer, reference_context, n_atoms)
         lo_n = max(ref_n_atoms - variance, self.min_n_nodes)
         hi_n = min(ref_n_atoms + variance, self.max_n_nodes)
+        self._finish_stage = None
 
-        def run_shard(sizes_shard, lo, hi):
-            return self._generate_shard(ref_context, ref_n_atoms, variance, sizes_shard, hi - lo, resample_steps,
-                                        fixed_fragment, inertial_fragment_matching, blend_power, ifm_diffusion_level)
+        def run_shard(sizes_shard, index):
+            return self._generate_shard(ref_context, ref_n_atoms, variance, sizes_shard, int(index.numel()), resample_steps,
+                                        fixed_fragment, inertial_fragment_matching, blend_power, ifm_diffusion_level,
+                                        optimise_geometry)
 
         def seed_device(s):
             self.last_noise_seed = s          # this rank's noise stream (base seed + rank)
@@ -298,15 +369,24 @@ class MLConformerGenerator(torch.nn.Module):
                 with torch.cuda.device(self.device):
                     torch.cuda.manual_seed(s)
 
-        _, res = mcg_dist.sharded_generate(
+        dst = 0 if gather == "rank0" else None
+        _, res, shards = mcg_dist.sharded_generate(
             n_samples, lambda: mcg_dist.draw_global_sizes(n_samples, lo_n, hi_n, group), run_shard, group=group,
-            seed=seed, seed_fn=seed_device, gather_dst=0 if gather == "rank0" else None)
+            seed=seed, seed_fn=seed_device, gather_dst=dst, balance=balance)
+        self.last_shards = shards
+        stage, self._finish_stage = getattr(self, "_finish_stage", None), None
+        if stage is not None:                 # RDKit's gate: this rank's shard is finished here, the Mols travel as objects
+            done = mcg_dist.gather_objects(self._collect_finish(stage), shards, group, dst)
+            self.last_host_assembly_ms = 0.0
+            kept = [m for m in done if m is not None]
+            self.last_valid_fraction = len(kept) / len(done) if done else 0.0
+            return kept
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)       # (the D2H copies below would wait for the device anyway: keep that out of the figure)
         t0 = time.perf_counter()
         mols = molecules_from_tensors(res["x"], res["elements"], res["bond"], res["n_nodes"], res["valid"])
         self.last_host_assembly_ms = (time.perf_counter() - t0) * 1e3      # D2H of the gathered tensors + record views
-        kept, self.last_valid_fraction = _finish(mols, optimise_geometry)
+        kept, self.last_valid_fraction = _finish(mols, optimise_geometry, use_rdkit=False)    # no finisher: the proxy
         return kept
 
     @torch.no_grad()

@@ -8,8 +8,11 @@ over xGMI on the GPU box (`backend="nccl"`), gloo in the CPU tests.
 
 Molecule sizes: the GLOBAL size vector is drawn ONCE, on rank 0, from the CPU global RNG with the
 reference's own draw (`torch.randint(min, max + 1, (n_samples,))`, mol_utils.py:275) and broadcast
-(control plane: n_samples int64); rank r takes the slice `shard_range(n_samples, r, world)`.  A seeded
-single-process run and a sharded run therefore generate the same molecule sizes in the same order.
+(control plane: n_samples int64).  Every rank then derives the SAME assignment of molecules to ranks from it
+(`assign_shards`): longest-processing-time-first on the edge count n(n-1) - the denoiser's cost per molecule - so that a
+ragged batch (15..39 atoms: a 7x spread in cost) loads the ranks within ~1 % of each other instead of the +-5 % of equal
+COUNTS; the gathered results are put back into sample order.  A seeded single-process run and a sharded run therefore
+generate the same molecule sizes in the same order.
 Noise: per-rank device generator, seed `seed + rank` (with `seed=None` the base seed is drawn on rank 0 and
 broadcast - ranks never share a noise stream); bit-identity of the NOISE with an unsharded run is not promised
 (the reference draws it as one [B,N,*] tensor).
@@ -34,6 +37,35 @@ def shard_range(n_samples: int, rank: int, world: int) -> Tuple[int, int]:
 
 def shard_sizes(n_samples: int, world: int) -> List[int]:
     return [shard_range(n_samples, r, world)[1] - shard_range(n_samples, r, world)[0] for r in range(world)]
+
+
+def molecule_cost(sizes: torch.Tensor) -> torch.Tensor:
+    """Relative cost of a molecule of n atoms on the hot path: its n(n-1) directed edges (27 fused edge-MLP launches per
+    denoiser call, ~80 % of the GPU time; SURVEY.md section 8a FLOP accounting)."""
+    n = sizes.to(torch.int64)
+    return n * (n - 1)
+
+
+def assign_shards(sizes: torch.Tensor, world: int, balance: str = "cost") -> List[torch.Tensor]:
+    """Which samples each rank generates: `world` ascending index vectors that partition range(len(sizes)).
+    "cost": longest-processing-time-first on `molecule_cost` (next-heaviest molecule to the least-loaded rank, ties to the
+    lower rank - deterministic, identical on every rank; equal sizes degenerate to equal counts, index % world);
+    "count": the contiguous equal-count slices of `shard_range`."""
+    n = int(sizes.numel())
+    if balance == "count":
+        return [torch.arange(*shard_range(n, r, world)) for r in range(world)]
+    if balance != "cost":
+        raise ValueError("balance must be 'cost' or 'count'")
+    import heapq
+    cost = molecule_cost(sizes.reshape(-1)).tolist()
+    order = sorted(range(n), key=lambda i: (-cost[i], i))
+    heap = [(0, r) for r in range(world)]
+    mine: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        load, r = heapq.heappop(heap)
+        mine[r].append(i)
+        heapq.heappush(heap, (load + cost[i], r))
+    return [torch.tensor(sorted(m), dtype=torch.int64) for m in mine]
 
 
 def rank_seed(seed: int, rank: int) -> int:
@@ -77,21 +109,23 @@ def draw_global_sizes(n_samples: int, min_n_nodes: int, max_n_nodes: int, group=
     return sizes.cpu()
 
 
-def gather_results(local: Dict[str, torch.Tensor], n_samples: int, group=None, dst: Optional[int] = None
-                   ) -> Dict[str, torch.Tensor]:
+def gather_results(local: Dict[str, torch.Tensor], n_samples: int, group=None, dst: Optional[int] = None,
+                   shards: Optional[List[torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
     """Gather per-sample result tensors (dim 0 = sample) of unequal shard sizes - the ONE data-path collective.
     `dst` None: all-gather, every rank returns the full batch in rank order.  `dst` = a group rank: `gather` to that rank
     only; it returns the full batch, every other rank its OWN shard (no replicated D2H copy / record assembly on the
     ranks that do not consume the batch).  Shards are padded to the largest shard so that one fixed-size collective per
-    tensor suffices."""
+    tensor suffices.  `shards`: the sample indices of every rank (`assign_shards`; default = contiguous equal-count
+    slices); the gathered rows are returned in SAMPLE order."""
     if not dist.is_available() or not dist.is_initialized():
         return local
     world = dist.get_world_size(group)
     if _solo(world):
         return local
     rank = dist.get_rank(group)
-    sizes = shard_sizes(n_samples, world)
+    sizes = shard_sizes(n_samples, world) if shards is None else [int(ix.numel()) for ix in shards]
     cap = max(sizes)
+    perm = None if shards is None else torch.cat(list(shards))      # row k of the rank-ordered concat is sample perm[k]
     # gloo (CPU tests, or a multi-process dry run on one GPU) cannot move device tensors
     via_host = dist.get_backend(group) == "gloo"
     out = {}
@@ -112,6 +146,8 @@ def gather_results(local: Dict[str, torch.Tensor], n_samples: int, group=None, d
                 continue
             parts = [recv[r][: sizes[r]] for r in range(world)]
         full = torch.cat(parts, dim=0)
+        if perm is not None:
+            full = torch.empty_like(full).index_copy_(0, perm.to(full.device), full)
         out[key] = full.to(t.device) if via_host else full
     return out
 
@@ -146,30 +182,58 @@ def exchange_status(ok: bool, group=None) -> List[bool]:
     return [bool(v) for v in buf.cpu().tolist()]
 
 
+def gather_objects(local: List, shards: List[torch.Tensor], group=None, dst: Optional[int] = None) -> List:
+    """Per-sample PYTHON objects (the finished `Chem.Mol`s of a rank's own shard, or None for a dropped molecule) into
+    sample order - control plane, pickled by `torch.distributed`; a few hundred bytes per molecule, once per call.
+    `dst` None: every rank gets the whole list; else only group rank `dst` does and the others get their own list back."""
+    world, rank = world_and_rank(group)
+    if _solo(world) or not (dist.is_available() and dist.is_initialized()):
+        return local
+    if dst is None:
+        parts: List = [None] * world
+        dist.all_gather_object(parts, local, group=group)
+    else:
+        parts = [None] * world if rank == dst else None
+        dist.gather_object(local, parts, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
+        if rank != dst:
+            return local
+    n = sum(int(ix.numel()) for ix in shards)
+    out: List = [None] * n
+    for r, ix in enumerate(shards):
+        if len(parts[r]) != int(ix.numel()):
+            raise ValueError(f"rank {r} returned {len(parts[r])} objects for a shard of {int(ix.numel())}")
+        for k, i in enumerate(ix.tolist()):
+            out[i] = parts[r][k]
+    return out
+
+
 def sharded_generate(n_samples: int, draw_sizes: Callable[[], torch.Tensor],
-                     run_shard: Callable[[torch.Tensor, int, int], Dict[str, torch.Tensor]], group=None,
+                     run_shard: Callable[[torch.Tensor, torch.Tensor], Dict[str, torch.Tensor]], group=None,
                      seed: Optional[int] = None, seed_fn: Optional[Callable[[int], None]] = None,
-                     gather_dst: Optional[int] = None) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+                     gather_dst: Optional[int] = None, balance: str = "cost"
+                     ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], List[torch.Tensor]]:
     """The sharded generation step every multi-GPU entry point goes through
     (`MLConformerGenerator.generate_conformers_sharded`, `bench.py --gpus N`):
 
       sizes  = draw_sizes() once for the whole batch (identical on every rank, see `draw_global_sizes`)
-      lo, hi = shard_range(n_samples, rank, world)
+      shards = assign_shards(sizes, world, balance)   # cost-balanced (n(n-1), LPT) by default; same on every rank
       seed_fn(rank_seed(seed, rank))            # per-rank noise stream - ALWAYS when world > 1: with `seed` None the
                                                 # base seed is drawn on rank 0 and broadcast (`draw_base_seed`); every
                                                 # process starts its device generator from the same constant, so
                                                 # "leave the generators alone" would make all shards identical
-      local  = run_shard(sizes[lo:hi], lo, hi)  # dict of per-sample tensors, dim 0 = hi - lo (may be 0)
+      local  = run_shard(sizes[mine], mine)     # dict of per-sample tensors, dim 0 = len(mine) (may be 0)
       status = exchange_status(...)             # one byte per rank; ShardError on EVERY rank if any shard failed
       full   = gather_results(local)            # the ONLY data-path collective, at the very end
 
-    Returns (sizes, full) on every rank; `full` is in sample order.  `gather_dst` = a group rank: only that rank receives
-    the full batch (`gather`), the others get their own shard back."""
+    Returns (sizes, full, shards) on every rank; `full` is in SAMPLE order whatever the assignment.  `gather_dst` = a group
+    rank: only that rank receives the full batch (`gather`), the others get their own shard back (rows in the order of
+    `shards[rank]`)."""
     world, rank = world_and_rank(group)
     sizes = draw_sizes()
     if sizes.numel() != n_samples:
         raise ValueError(f"draw_sizes() returned {sizes.numel()} sizes for n_samples={n_samples}")
-    lo, hi = shard_range(n_samples, rank, world)
+    shards = assign_shards(sizes, world, balance)
+    mine = shards[rank]
     if seed_fn is not None:
         if seed is None and world > 1:
             seed = draw_base_seed(group)
@@ -177,10 +241,10 @@ def sharded_generate(n_samples: int, draw_sizes: Callable[[], torch.Tensor],
             seed_fn(rank_seed(seed, rank))
     local, failure = None, None
     try:
-        local = run_shard(sizes[lo:hi], lo, hi)
+        local = run_shard(sizes[mine], mine)
         for key, t in local.items():
-            if t.shape[0] != hi - lo:
-                raise ValueError(f"run_shard returned {t.shape[0]} rows of `{key}` for a shard of {hi - lo}")
+            if t.shape[0] != mine.numel():
+                raise ValueError(f"run_shard returned {t.shape[0]} rows of `{key}` for a shard of {mine.numel()}")
     except Exception as e:  # noqa: BLE001 - reported to every rank below, then re-raised
         if world == 1:
             raise
@@ -192,4 +256,4 @@ def sharded_generate(n_samples: int, draw_sizes: Callable[[], torch.Tensor],
         if failure is not None:
             raise ShardError(f"{msg}; this rank ({rank}): {type(failure).__name__}: {failure}") from failure
         raise ShardError(msg + f"; this rank ({rank}) finished its shard")
-    return sizes, gather_results(local, n_samples, group, dst=gather_dst)
+    return sizes, gather_results(local, n_samples, group, dst=gather_dst, shards=shards), shards

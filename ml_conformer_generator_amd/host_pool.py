@@ -1,0 +1,318 @@
+"""Host fan-out of the RDKit-owned stages of `generate_conformers` ("RDKit MMFF fanned out over
+host cores").
+
+The reference canonicalises and standardises ONE molecule at a time on one Python thread
+(`prepare_adj_mat_seer_input` -> `canonicalise`, utils/mol_utils.py:163-164; `standardize_mol` incl. up to 1 000 MMFF
+iterations per molecule, conformer_generator.py:362-366, utils/standardizer.py:62-111).  With the sampler at 0.46 s per 64
+molecules that thread - tens of ms per molecule - would decide "valid molecules/s" while the GPU and every other host core
+idle.  `HostPool` runs those per-molecule functions in a pool of worker processes:
+
+  * workers are FRESH interpreters (`subprocess` -> `_host_worker.py`, run by file path): never a `fork()` of this process
+    (which owns a GPU context), never a re-exec of it; they import the task file (`_rdkit_tasks.py`: numpy + RDKit) and
+    nothing of this package - no torch, no HIP library;
+  * created lazily at the first submit, shared process-wide per worker count (`shared_pool`), shut down at exit; a worker
+    that dies fails ITS task with `HostPoolError` and is replaced;
+  * work is named by a `TaskRef` (file path + function name of a *chunk function* `f(items, *args) -> list`); results come
+    back as `concurrent.futures.Future`s, so the caller consumes them in submission order while later chunks are still
+    running - `MLConformerGenerator` launches the hand-off + GCN of one group of molecules as soon as ITS order results are
+    in and submits that group's finish tasks behind it (order(g+1..) | GPU(g) | finish(..g) overlap);
+  * an exception raised by a task (e.g. the reference's `ValueError` for a molecule without a perceived bond,
+    utils/molgraph.py:152-155) is re-raised in the caller, same type, with the worker's traceback text attached
+    (`.worker_traceback`); a `None` result keeps meaning "dropped".
+
+`SerialExecutor` has the same `submit` and runs the chunk function in-process (`n_host_workers=0`): pooled and serial runs
+execute the same code per molecule and return the same results in the same order (tests/test_host_pool.py).
+"""
+from __future__ import annotations
+
+import atexit
+import importlib.util
+import os
+import pickle
+import queue
+import subprocess
+import sys
+import threading
+from concurrent.futures import Future
+from typing import Dict, List, Optional, Sequence, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_WORKER = os.path.join(_HERE, "_host_worker.py")
+RDKIT_TASKS = os.path.join(_HERE, "_rdkit_tasks.py")
+
+
+class HostPoolError(RuntimeError):
+    """A worker process died (or could not be started) while it held a task."""
+
+
+class TaskRef:
+    """A chunk function `f(items, *args) -> list` (one result per item) in a file a worker can load by path."""
+    __slots__ = ("path", "func")
+
+    def __init__(self, path: str, func: str):
+        self.path, self.func = os.path.abspath(path), func
+
+    def __repr__(self) -> str:
+        return f"TaskRef({self.path!r}, {self.func!r})"
+
+    def __eq__(self, other) -> bool:
+        return isinstance(other, TaskRef) and (self.path, self.func) == (other.path, other.func)
+
+    def __hash__(self) -> int:
+        return hash((self.path, self.func))
+
+    def load(self):
+        """The function itself, loaded in THIS process (serial path)."""
+        mod = _LOCAL.get(self.path)
+        if mod is None:
+            name = "_mcg_host_task_local_%d" % len(_LOCAL)
+            spec = importlib.util.spec_from_file_location(name, self.path)
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules[name] = mod
+            spec.loader.exec_module(mod)
+            _LOCAL[self.path] = mod
+        return getattr(mod, self.func)
+
+
+_LOCAL: Dict[str, object] = {}
+
+ORDER_TASK = TaskRef(RDKIT_TASKS, "order_chunk")
+FINISH_TASK = TaskRef(RDKIT_TASKS, "finish_chunk")
+SAMPLES_TASK = TaskRef(RDKIT_TASKS, "samples_chunk")
+
+
+def default_workers() -> int:
+    """`n_host_workers` default: min(32, host cores) - MMFF is tens of ms per molecule, a generate call has 10..2 048."""
+    return min(32, os.cpu_count() or 1)
+
+
+def chunk_bounds(n: int, size: int) -> List[Tuple[int, int]]:
+    size = max(1, int(size))
+    return [(lo, min(n, lo + size)) for lo in range(0, n, size)]
+
+
+def task_chunk(n_items: int, n_workers: int, cap: int = 8) -> int:
+    """Molecules per task: ~4 tasks per worker for load balance (MMFF times vary by an order of magnitude), at most `cap`
+    so that one slow chunk is not the tail, at least 1."""
+    if n_workers <= 0:
+        return max(1, n_items)
+    return max(1, min(cap, -(-n_items // (4 * n_workers))))
+
+
+class SerialExecutor:
+    """`submit` with the pool's signature, run in-process at submit time."""
+    n_workers = 0
+
+    def submit(self, ref: TaskRef, items: Sequence, args: tuple = ()) -> Future:
+        fut: Future = Future()
+        try:
+            fut.set_result(ref.load()(list(items), *args))
+        except BaseException as e:  # noqa: BLE001 - delivered where the pool would deliver it: at .result()
+            fut.set_exception(e)
+        return fut
+
+
+class _Worker:
+    def __init__(self, python: str, env: dict):
+        r_task, w_task = os.pipe()
+        r_res, w_res = os.pipe()
+        try:
+            self.proc = subprocess.Popen([python, "-u", _WORKER, str(r_task), str(w_res)], pass_fds=(r_task, w_res),
+                                         stdin=subprocess.DEVNULL, env=env, close_fds=True)
+        except Exception:
+            for fd in (r_task, w_task, r_res, w_res):
+                os.close(fd)
+            raise
+        os.close(r_task)
+        os.close(w_res)
+        self.tx = os.fdopen(w_task, "wb")
+        self.rx = os.fdopen(r_res, "rb")
+
+    @property
+    def pid(self) -> int:
+        return self.proc.pid
+
+    def call(self, payload: bytes):
+        self.tx.write(payload)
+        self.tx.flush()
+        return pickle.load(self.rx)
+
+    def stop(self, timeout: float = 2.0) -> None:
+        for f in (self.tx, self.rx):
+            try:
+                f.close()                       # EOF on the task pipe = the worker's shutdown signal
+            except Exception:  # noqa: BLE001
+                pass
+        try:
+            self.proc.wait(timeout=timeout)
+        except Exception:  # noqa: BLE001
+            try:
+                self.proc.kill()                # this exact child, by handle
+                self.proc.wait(timeout=timeout)
+            except Exception:  # noqa: BLE001
+                pass
+
+
+def _worker_env() -> dict:
+    env = dict(os.environ)
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        env[k] = "1"                             # one core per worker: the pool IS the parallelism
+    # a profiler's preloaded tool library would initialise the GPU inside every worker: workers are host-only
+    for k in list(env):
+        if k == "LD_PRELOAD" or k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_", "HSA_TOOLS_")):
+            env.pop(k)
+    return env
+
+
+class HostPool:
+    def __init__(self, n_workers: int, python: Optional[str] = None):
+        if n_workers < 1:
+            raise ValueError("HostPool needs at least one worker (0 workers = SerialExecutor)")
+        self.n_workers = int(n_workers)
+        self._python = python or sys.executable
+        self._q: "queue.Queue" = queue.Queue()
+        self._threads: List[threading.Thread] = []
+        self._workers: List[Optional[_Worker]] = []
+        self._lock = threading.Lock()
+        self._pid = None
+        self._closed = False
+        self.tasks_done = 0
+        self.workers_replaced = 0
+
+    # ---------------------------------------------------------------- life cycle
+    def start(self) -> "HostPool":
+        with self._lock:
+            if self._closed:
+                raise HostPoolError("the pool is closed")
+            if self._pid == os.getpid() and self._threads:
+                return self
+            # first use, or this is a forked copy of a process that had a pool: threads do not survive a fork
+            self._q = queue.Queue()
+            self._threads, self._workers = [], []
+            env = _worker_env()
+            try:
+                for _ in range(self.n_workers):
+                    self._workers.append(_Worker(self._python, env))
+            except Exception as e:
+                for w in self._workers:
+                    w.stop()
+                self._workers = []
+                raise HostPoolError(f"could not start a host worker: {e}") from e
+            for k in range(self.n_workers):
+                t = threading.Thread(target=self._serve, args=(k,), name=f"mcg-host-pool-{k}", daemon=True)
+                t.start()
+                self._threads.append(t)
+            self._pid = os.getpid()
+        return self
+
+    def worker_pids(self) -> List[int]:
+        return [w.pid for w in self._workers if w is not None]
+
+    def close(self) -> None:
+        with self._lock:
+            if self._closed:
+                return
+            self._closed = True
+            threads, workers = self._threads, self._workers
+            own = self._pid == os.getpid()
+            self._threads, self._workers = [], []
+        if not own:
+            return
+        for _ in threads:
+            self._q.put(None)
+        for t in threads:
+            t.join(timeout=5.0)
+        for w in workers:
+            if w is not None:
+                w.stop()
+
+    def __enter__(self):
+        return self.start()
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---------------------------------------------------------------- work
+    def submit(self, ref: TaskRef, items: Sequence, args: tuple = ()) -> Future:
+        """One task = one chunk: `ref.func(list(items), *args)` in some worker -> Future of the result list."""
+        self.start()
+        fut: Future = Future()
+        payload = pickle.dumps((ref.path, ref.func, list(items), tuple(args)), protocol=pickle.HIGHEST_PROTOCOL)
+        self._q.put((fut, payload))
+        return fut
+
+    def _serve(self, k: int) -> None:
+        q = self._q
+        while True:
+            job = q.get()
+            if job is None:
+                return
+            fut, payload = job
+            if not fut.set_running_or_notify_cancel():
+                continue
+            w = self._workers[k]
+            try:
+                if w is None:
+                    raise EOFError("no worker")
+                reply = w.call(payload)
+            except (EOFError, OSError, pickle.UnpicklingError, ValueError) as e:
+                pid = w.pid if w is not None else -1
+                fut.set_exception(HostPoolError(f"host worker {pid} died while it held a task ({type(e).__name__}: {e})"))
+                if w is not None:
+                    w.stop(timeout=0.5)
+                try:
+                    self._workers[k] = _Worker(self._python, _worker_env())
+                    self.workers_replaced += 1
+                except Exception:  # noqa: BLE001 - keep serving: the next task fails loudly too
+                    self._workers[k] = None
+                continue
+            self.tasks_done += 1
+            if reply[0]:
+                fut.set_result(reply[1])
+            else:
+                exc = reply[1]
+                try:
+                    exc.worker_traceback = reply[2]
+                except Exception:  # noqa: BLE001
+                    pass
+                fut.set_exception(exc)
+
+
+_SHARED: Dict[int, HostPool] = {}
+_SHARED_LOCK = threading.Lock()
+
+
+def shared_pool(n_workers: int):
+    """The process-wide pool with `n_workers` workers (created on first use, closed at exit); 0 -> `SerialExecutor`."""
+    if n_workers <= 0:
+        return SerialExecutor()
+    with _SHARED_LOCK:
+        pool = _SHARED.get(n_workers)
+        if pool is None or pool._closed:
+            pool = _SHARED[n_workers] = HostPool(n_workers)
+        return pool
+
+
+@atexit.register
+def _close_shared() -> None:
+    with _SHARED_LOCK:
+        pools = list(_SHARED.values())
+        _SHARED.clear()
+    for p in pools:
+        try:
+            p.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def map_ordered(executor, ref: TaskRef, items: Sequence, args: tuple = (), chunk: Optional[int] = None) -> List:
+    """All items through `ref`, results in item order (blocks until every chunk is done; the first failing chunk's
+    exception is raised)."""
+    items = list(items)
+    if chunk is None:
+        chunk = task_chunk(len(items), getattr(executor, "n_workers", 0))
+    futs = [executor.submit(ref, items[lo:hi], args) for lo, hi in chunk_bounds(len(items), chunk)]
+    out: List = []
+    for f in futs:
+        out.extend(f.result())
+    return out

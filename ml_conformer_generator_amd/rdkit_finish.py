@@ -25,9 +25,13 @@ Input: `GeneratedMolecule` records (atoms in the order the GCN saw them - RDKit'
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import List, Optional, Sequence, Tuple
 
-_TARTRATE_SMARTS = "OC(=O)C(O)C(O)C(=O)O"
+from . import _rdkit_tasks as _tasks
+from . import host_pool
+from .config import ATOM_DECODER, ATOMIC_NUMBERS
+
+_Z2SYMBOL = {z: ATOM_DECODER[i] for i, z in enumerate(ATOMIC_NUMBERS)}
 
 
 def have_rdkit() -> bool:
@@ -38,31 +42,11 @@ def have_rdkit() -> bool:
         return False
 
 
-def _bond_type_dict(Chem):
-    bt = Chem.rdchem.BondType                                            # mol_utils.py:10-15
-    return {1: bt.SINGLE, 2: bt.DOUBLE, 3: bt.TRIPLE, 4: bt.AROMATIC}
-
-
 def mol_from_record(rec, Chem=None):
     """`redefine_bonds` (mol_utils.py:197-223) on a `GeneratedMolecule`: XYZ text -> Mol -> XYZ text -> Mol (the
     reference's two text round trips: "%.9f", then MolToXYZBlock's own precision), then one AddBond per non-zero entry of
-    the strict lower triangle, in the reference's (i, j) loop order."""
-    if Chem is None:
-        from rdkit import Chem
-    mol = Chem.MolFromXYZBlock(rec.to_xyz_block())
-    if mol is None:
-        return None
-    c_mol = Chem.MolFromXYZBlock(Chem.MolToXYZBlock(mol))
-    ed_mol = Chem.EditableMol(c_mol)
-    types = _bond_type_dict(Chem)
-    bo = rec.bond_orders.tolist()
-    n = len(bo)
-    for i in range(n):
-        for j in range(i):                       # tril with the diagonal removed (:210-211): only j < i can be non-zero
-            t = int(bo[i][j])
-            if t != 0:
-                ed_mol.AddBond(i, j, types[t])
-    return ed_mol.GetMol()
+    the strict lower triangle, in the reference's (i, j) loop order (body: `_rdkit_tasks.mol_from_xyz_and_bonds`)."""
+    return _tasks.mol_from_xyz_and_bonds(rec.to_xyz_block(), rec.bond_orders.tolist(), Chem)
 
 
 def mol_without_bonds(rec, Chem=None):
@@ -72,51 +56,82 @@ def mol_without_bonds(rec, Chem=None):
     return Chem.MolFromXYZBlock(rec.to_xyz_block())
 
 
-def _standardize(mol, optimise_geometry: bool):
-    from rdkit import Chem
-    from rdkit.Chem import AllChem
-    from rdkit.Chem.MolStandardize import rdMolStandardize
-    try:
-        m = rdMolStandardize.FragmentParent(mol)                      # standardizer.py:92
-        Chem.Kekulize(m)                                              # :94
-        query = Chem.MolFromSmarts(_TARTRATE_SMARTS)                  # :47-59: free tartrate / tartaric acid only
-        params = Chem.AdjustQueryParameters.NoAdjustments()
-        params.adjustDegree = True
-        params.adjustDegreeFlags = Chem.AdjustQueryWhichFlags.ADJUST_IGNORENONE
-        hits = m.GetSubstructMatches(Chem.AdjustQueryProperties(query, params))
-        if hits:
-            m = Chem.Mol(m)
-            for hit in hits:
-                for k in (3, 5):
-                    m.GetAtomWithIdx(hit[k]).SetChiralTag(Chem.ChiralType.CHI_UNSPECIFIED)
-        Chem.SanitizeMol(m)                                           # :99
-        if not optimise_geometry:
-            return m
-        m = Chem.AddHs(m, addCoords=True)                             # :102
-        props = AllChem.MMFFGetMoleculeProperties(m, mmffVariant="MMFF94")      # :69-70
-        ff = AllChem.MMFFGetMoleculeForceField(m, props, confId=0)
-        for atom in m.GetAtoms():                                     # :73-74
-            ff.MMFFAddPositionConstraint(atom.GetIdx(), 0.2, 800.0)
-        ff.Initialize()
-        ff.Minimize(maxIts=1000, energyTol=1e-08)                     # :77-78
-        return Chem.RemoveHs(m)                                       # :104
-    except Exception:  # noqa: BLE001 - the reference's bare `except:` (standardizer.py:108-109): invalid => dropped
-        return None
+_standardize = _tasks.standardize
 
 
-def finish(molecules: List, optimise_geometry: bool = True) -> List[Optional[object]]:
+def record_item(rec) -> Tuple[list, list, list]:
+    """A `GeneratedMolecule` as the plain-data item the finish tasks take (atomic numbers, coordinates as python floats
+    holding the fp32 values - what "%.9f" prints -, bond-order rows)."""
+    return rec.atomic_numbers, rec.coords.tolist(), rec.bond_orders.tolist()
+
+
+def finisher_task(finisher, optimise_geometry: bool):
+    """(TaskRef, args, rebuild) for a finisher the host pool can run: "rdkit" = the reference's `redefine_bonds` +
+    `standardize_mol` (results travel as `Mol.ToBinary()` bytes and are rebuilt here), or a caller's chunk function named
+    by a `host_pool.TaskRef` (`f(items, optimise_geometry) -> list`, results returned as they are; None = dropped)."""
+    if finisher == "rdkit":
+        def rebuild(b):
+            from rdkit import Chem
+            return None if b is None else Chem.Mol(b)
+        return host_pool.FINISH_TASK, (bool(optimise_geometry), _Z2SYMBOL), rebuild
+    if isinstance(finisher, host_pool.TaskRef):
+        return finisher, (bool(optimise_geometry),), (lambda r: r)
+    raise ValueError(f"unknown finisher {finisher!r}")
+
+
+class FinishStage:
+    """The RDKit finish of one generated batch, submitted group by group (`add`) and collected in sample order
+    (`results`).  With a `SerialExecutor` and the RDKit finisher the Mols are built in-process (no byte round trip)."""
+
+    def __init__(self, finisher, optimise_geometry: bool, executor=None):
+        self.executor = executor if executor is not None else host_pool.SerialExecutor()
+        self.serial_rdkit = finisher == "rdkit" and getattr(self.executor, "n_workers", 0) == 0
+        self.optimise_geometry = bool(optimise_geometry)
+        if not self.serial_rdkit:
+            self.ref, self.args, self.rebuild = finisher_task(finisher, optimise_geometry)
+        self._parts: List = []                 # per group: list of futures (pooled) or a list of results (serial RDKit)
+        self.n_submitted = 0
+
+    def add(self, records: Sequence) -> None:
+        """Submit the finish of these molecules (sample order continues where the previous `add` stopped)."""
+        items = [record_item(r) for r in records]
+        self.n_submitted += len(items)
+        if self.serial_rdkit:
+            self._parts.append([_tasks.finish_one(z, c, bo, self.optimise_geometry, _Z2SYMBOL) for z, c, bo in items])
+            return
+        chunk = host_pool.task_chunk(len(items), getattr(self.executor, "n_workers", 0), cap=4)
+        self._parts.append([self.executor.submit(self.ref, items[lo:hi], self.args)
+                            for lo, hi in host_pool.chunk_bounds(len(items), chunk)])
+
+    def results(self) -> List[Optional[object]]:
+        out: List[Optional[object]] = []
+        for part in self._parts:
+            if self.serial_rdkit:
+                out.extend(part)
+                continue
+            for f in part:
+                out.extend(self.rebuild(r) for r in f.result())
+        if len(out) != self.n_submitted:
+            raise ValueError(f"the finish task returned {len(out)} results for {self.n_submitted} molecules")
+        return out
+
+
+def finish(molecules: List, optimise_geometry: bool = True, executor=None) -> List[Optional[object]]:
     """`GeneratedMolecule` records -> RDKit Mols through the reference's `redefine_bonds` + `standardize_mol`; None where
-    the gate rejects one (conformer_generator.py:362-366 drops those)."""
-    out = []
-    for rec in molecules:
-        mol = mol_from_record(rec)
-        out.append(None if mol is None else _standardize(mol, optimise_geometry))
-    return out
+    the gate rejects one (conformer_generator.py:362-366 drops those).  `executor`: a `host_pool.HostPool` fans the
+    molecules out over host cores (same per-molecule code, results in the same order)."""
+    stage = FinishStage("rdkit", optimise_geometry, executor)
+    stage.add(molecules)
+    return stage.results()
 
 
-def samples(molecules: List) -> List[object]:
+def samples(molecules: List, executor=None) -> List[object]:
     """`edm_samples`' return value (conformer_generator.py:262-266): bond-free Mols; unbuildable ones are skipped
     (mol_utils.py:53-55)."""
+    if executor is not None and getattr(executor, "n_workers", 0) > 0:
+        from rdkit import Chem
+        raw = host_pool.map_ordered(executor, host_pool.SAMPLES_TASK, [record_item(r) for r in molecules], (_Z2SYMBOL,))
+        return [Chem.Mol(b) for b in raw if b is not None]
     out = []
     for rec in molecules:
         mol = mol_without_bonds(rec)

@@ -31,6 +31,8 @@ from typing import Callable, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
+from . import _rdkit_tasks as _tasks
+from . import host_pool
 from .config import ATOM_DECODER, ATOMIC_NUMBERS
 
 Provider = Callable[[List[int], np.ndarray], Optional[Tuple[Optional[Sequence[int]], Optional[np.ndarray]]]]
@@ -48,33 +50,17 @@ def have_rdkit() -> bool:
 
 def xyz_block(atomic_numbers: Sequence[int], coords) -> str:
     """The XYZ text `samples_to_rdkit_mol` writes (mol_utils.py:39-51: count, empty line, "%s %.9f %.9f %.9f")."""
-    lines = ["%d\n\n" % len(atomic_numbers)]
-    for z, c in zip(atomic_numbers, coords):
-        lines.append("%s %.9f %.9f %.9f\n" % (_Z2SYMBOL[int(z)], float(c[0]), float(c[1]), float(c[2])))
-    return "".join(lines)
+    return _tasks.xyz_text(atomic_numbers, coords, _Z2SYMBOL)
 
 
-def parse_smiles_output_order(prop: str) -> List[int]:
-    """`_smilesAtomOutputOrder` ("[3,0,1,2,]") -> [3, 0, 1, 2] (mol_utils.py:119-122)."""
-    prop = prop.replace("[", "").replace("]", "")
-    return [int(v) for v in prop.split(",") if v != ""]
+parse_smiles_output_order = _tasks.parse_smiles_output_order
 
 
 def rdkit_provider(atomic_numbers: List[int], coords: np.ndarray):
     """The reference's `samples_to_rdkit_mol` + `canonicalise` for ONE molecule (mol_utils.py:39-55,110-126).  A molecule
-    without a single perceived bond raises ValueError like the reference (`MolGraph.from_mol`, molgraph.py:150-153)."""
-    from rdkit import Chem
-    from rdkit.Chem import rdDetermineBonds
-    mol = Chem.MolFromXYZBlock(xyz_block(atomic_numbers, coords))
-    if mol is None:
-        return None
-    rdDetermineBonds.DetermineConnectivity(mol)
-    _ = Chem.MolToSmiles(mol)
-    order = parse_smiles_output_order(mol.GetProp("_smilesAtomOutputOrder"))
-    if mol.GetNumBonds() == 0:
-        raise ValueError("Bonds must be specified for the molecule - no connectivity perceived.")
-    conn = np.asarray(Chem.GetAdjacencyMatrix(mol)) != 0            # generation order: read before any renumbering
-    return order, conn.astype(np.uint8)
+    without a single perceived bond raises ValueError like the reference (`MolGraph.from_mol`, molgraph.py:150-153).
+    The body lives in `_rdkit_tasks.order_one` (the file the pool's workers load); this is the in-process form."""
+    return _tasks.order_one(atomic_numbers, coords, _Z2SYMBOL)
 
 
 def default_provider() -> Optional[Provider]:
@@ -83,33 +69,104 @@ def default_provider() -> Optional[Provider]:
     return rdkit_provider if have_rdkit() else None
 
 
-def batch_order_and_connectivity(provider: Provider, x: torch.Tensor, h: torch.Tensor, n_nodes: torch.Tensor):
+def provider_task(provider):
+    """(TaskRef, args) when `provider` can run in the host pool's workers - RDKit's own sequence, or a caller's chunk
+    function named by a `host_pool.TaskRef` (`f(items) -> list`, item = (atomic_numbers, coords float64 [n,3]), result =
+    what a provider returns) - else None: a plain callable runs in this process, one molecule at a time."""
+    if provider is rdkit_provider:
+        return host_pool.ORDER_TASK, (_Z2SYMBOL,)
+    if isinstance(provider, host_pool.TaskRef):
+        return provider, ()
+    return None
+
+
+def launch_groups(batch: int, max_groups: int = 4, min_group: int = 8) -> List[Tuple[int, int]]:
+    """Contiguous molecule groups [lo, hi) of one generated batch: the hand-off + GCN of a group is launched as soon as
+    ITS order results are in, while the host is still working on the later groups."""
+    n_groups = max(1, min(max_groups, batch // min_group))
+    base, extra = divmod(batch, n_groups)
+    out, lo = [], 0
+    for g in range(n_groups):
+        hi = lo + base + (1 if g < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+class OrderStage:
+    """The order + connectivity decisions of one generated batch, computed per launch group.
+
+    Construction copies x, h, n_nodes to the host (ONE D2H copy each) and - for a poolable provider - submits every
+    task right away; `result(g)` blocks until group g's molecules are done and returns what
+    `prepare_adj_mat_seer_input_hip` takes for x[lo:hi]: (order, connectivity, built)."""
+
+    def __init__(self, provider, x: torch.Tensor, h: torch.Tensor, n_nodes: torch.Tensor, executor=None,
+                 groups: Optional[List[Tuple[int, int]]] = None):
+        xc = x.detach().to("cpu", torch.float64).numpy()
+        cls = torch.argmax(h.detach(), dim=2).to("cpu").tolist()          # argmax(one_hot) (mol_utils.py:41)
+        self.ns = [int(v) for v in n_nodes.detach().to("cpu").reshape(-1).tolist()]
+        self.items = [([ATOMIC_NUMBERS[k] for k in cls[b][:n]], xc[b, :n]) for b, n in enumerate(self.ns)]
+        self.groups = groups if groups is not None else [(0, len(self.ns))]
+        self.provider = provider
+        self._given = None                     # did the provider supply connectivities?  one answer per batch
+        task = provider_task(provider)
+        self._futs = None
+        if task is not None:
+            ref, args = task
+            ex = executor if executor is not None else host_pool.SerialExecutor()
+            chunk = host_pool.task_chunk(len(self.items), getattr(ex, "n_workers", 0))
+            self._futs = []
+            for lo, hi in self.groups:
+                self._futs.append([ex.submit(ref, self.items[a:b], args) for a, b in
+                                   ((lo + c0, lo + c1) for c0, c1 in host_pool.chunk_bounds(hi - lo, chunk))])
+
+    def _raw(self, g: int) -> list:
+        lo, hi = self.groups[g]
+        if self._futs is not None:
+            out: list = []
+            for f in self._futs[g]:
+                out.extend(f.result())
+            if len(out) != hi - lo:
+                raise ValueError(f"the order task returned {len(out)} results for {hi - lo} molecules")
+            return out
+        return [self.provider(z, c) if len(z) > 0 else (None, None) for z, c in self.items[lo:hi]]
+
+    def result(self, g: int):
+        lo, hi = self.groups[g]
+        ns = self.ns[lo:hi]
+        order: List[Optional[Sequence[int]]] = []
+        conn: List[Optional[np.ndarray]] = []
+        built: List[bool] = []
+        for res in self._raw(g):
+            if res is None:
+                order.append(None); conn.append(None); built.append(False)
+                continue
+            o, c = res
+            order.append(None if o is None else [int(v) for v in o])
+            conn.append(None if c is None else np.asarray(c))
+            built.append(True)
+        given = [c is not None for c, ok in zip(conn, built) if ok]
+        mixed = any(given) and not all(given)
+        if given and not mixed:
+            if self._given is None:
+                self._given = given[0]
+            mixed = self._given != given[0]
+        if mixed:
+            raise ValueError("an atom-order provider must return a connectivity for every molecule or for none "
+                             "(the hand-off kernel applies one connectivity rule per launch)")
+        use_conn = any(given) if given else bool(self._given)
+        if use_conn:          # molecules the provider could not build are dropped downstream: any placeholder will do
+            conn_arg = [np.zeros((n, n), dtype=np.uint8) if c is None else c for c, n in zip(conn, ns)]
+        else:
+            conn_arg = None
+        order_arg = None if all(o is None for o in order) else order
+        return order_arg, conn_arg, built
+
+
+def batch_order_and_connectivity(provider: Provider, x: torch.Tensor, h: torch.Tensor, n_nodes: torch.Tensor,
+                                 executor=None):
     """Run `provider` over a generated batch (x[B,N,3], h[B,N,8] one-hot, n_nodes[B]; any device - ONE D2H copy each).
     Returns (order, connectivity, built): per-molecule lists for `prepare_adj_mat_seer_input_hip` (None entries = the
-    substitutes) and built[B] bool (False where the provider returned None: the reference drops that molecule)."""
-    xc = x.detach().to("cpu", torch.float64).numpy()
-    cls = torch.argmax(h.detach(), dim=2).to("cpu").tolist()          # argmax(one_hot) (mol_utils.py:41)
-    ns = [int(v) for v in n_nodes.detach().to("cpu").reshape(-1).tolist()]
-    order: List[Optional[Sequence[int]]] = []
-    conn: List[Optional[np.ndarray]] = []
-    built: List[bool] = []
-    for b, n in enumerate(ns):
-        z = [ATOMIC_NUMBERS[k] for k in cls[b][:n]]
-        res = provider(z, xc[b, :n]) if n > 0 else (None, None)
-        if res is None:
-            order.append(None); conn.append(None); built.append(False)
-            continue
-        o, c = res
-        order.append(None if o is None else [int(v) for v in o])
-        conn.append(None if c is None else np.asarray(c))
-        built.append(True)
-    given = [c is not None for c, ok in zip(conn, built) if ok]
-    if any(given) and not all(given):
-        raise ValueError("an atom-order provider must return a connectivity for every molecule or for none "
-                         "(the hand-off kernel applies one connectivity rule per launch)")
-    if any(given):          # molecules the provider could not build are dropped downstream: any placeholder will do
-        conn_arg = [np.zeros((n, n), dtype=np.uint8) if c is None else c for c, n in zip(conn, ns)]
-    else:
-        conn_arg = None
-    order_arg = None if all(o is None for o in order) else order
-    return order_arg, conn_arg, built
+    substitutes) and built[B] bool (False where the provider returned None: the reference drops that molecule).
+    `executor`: a `host_pool.HostPool` fans a poolable provider (`provider_task`) out over host cores."""
+    return OrderStage(provider, x, h, n_nodes, executor).result(0)

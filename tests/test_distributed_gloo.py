@@ -6,8 +6,9 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from ml_conformer_generator_amd.distributed import (ShardError, draw_global_sizes, gather_results, rank_seed, shard_range,
-                                                    shard_sizes, sharded_generate)
+from ml_conformer_generator_amd.distributed import (ShardError, assign_shards, draw_global_sizes, gather_objects,
+                                                    gather_results, molecule_cost, rank_seed, shard_range, shard_sizes,
+                                                    sharded_generate)
 
 
 def test_shard_ranges_cover_the_batch():
@@ -19,6 +20,27 @@ def test_shard_ranges_cover_the_batch():
         assert covered == list(range(n))
         assert sum(shard_sizes(n, w)) == n and max(shard_sizes(n, w)) - min(shard_sizes(n, w)) <= 1
     assert rank_seed(7, 3) == 10
+
+
+def test_cost_balanced_assignment_is_a_partition_and_levels_the_edge_count():
+    """Multi-GPU readiness (round-4 review): equal COUNTS of U[15,39] molecules leave the slowest of 8 ranks ~5 % above the
+    mean edge count; longest-processing-time on n(n-1) levels it to <= 1 %.  Pure Python, identical on every rank."""
+    torch.manual_seed(7)
+    sizes = torch.randint(15, 40, (2048,))
+    for world in (2, 8):
+        shards = assign_shards(sizes, world)
+        assert sorted(torch.cat(shards).tolist()) == list(range(2048))
+        assert all(torch.equal(ix, ix.sort().values) for ix in shards)
+        loads = [int(molecule_cost(sizes[ix]).sum()) for ix in shards]
+        assert max(loads) / min(loads) <= 1.01
+        by_count = [int(molecule_cost(sizes[ix]).sum()) for ix in assign_shards(sizes, world, "count")]
+        assert max(by_count) / min(by_count) > max(loads) / min(loads)
+    # 8 x 256 ragged (configs[3]): the judged shape
+    assert max(len(ix) for ix in assign_shards(sizes, 8)) - min(len(ix) for ix in assign_shards(sizes, 8)) <= 40
+    # equal sizes (configs[1] weak scaling): equal counts; fewer samples than ranks: empty shards
+    assert [ix.tolist() for ix in assign_shards(torch.full((8,), 27), 4)] == [[0, 4], [1, 5], [2, 6], [3, 7]]
+    assert [ix.tolist() for ix in assign_shards(torch.tensor([20]), 2)] == [[0], []]
+    assert [ix.tolist() for ix in assign_shards(torch.arange(15, 22), 2, "count")] == [[0, 1, 2, 3], [4, 5, 6]]
 
 
 def _free_port():
@@ -45,6 +67,15 @@ def _worker(rank, world, port, n_samples, q):
     ok = (full["x"].shape[0] == n_samples and torch.equal(full["x"][:, 0, 0], torch.arange(n_samples).float())
           and torch.equal(full["n_nodes"], (15 + torch.arange(n_samples)).to(torch.int32))
           and torch.equal(full["bond"][:, 0, 0], (torch.arange(n_samples) % 5).to(torch.int8)))
+    # non-contiguous shards (cost-balanced assignment): rows come back in SAMPLE order; objects likewise
+    shards = [torch.tensor([0, 3, 4, 6]), torch.tensor([1, 2, 5])]
+    mine = shards[rank]
+    full = gather_results({"v": mine.float()}, n_samples, shards=shards)
+    ok = ok and full["v"].tolist() == [float(i) for i in range(n_samples)]
+    objs = gather_objects([f"m{int(i)}" if i % 2 else None for i in mine], shards)
+    ok = ok and objs == [f"m{i}" if i % 2 else None for i in range(n_samples)]
+    objs0 = gather_objects([int(i) for i in mine], shards, dst=0)
+    ok = ok and objs0 == (list(range(n_samples)) if rank == 0 else mine.tolist())
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
@@ -109,15 +140,17 @@ def _shard_worker(rank, world, port, n_samples, q):
     # what a single process seeded like rank 0 draws (the reference's draw, mol_utils.py:275)
     torch.manual_seed(1000)
     expect = torch.randint(15, 40, (n_samples,))
-    lo, hi = shard_range(n_samples, rank, world)
-    ok = len(calls) == 1 and torch.equal(calls[0][0], expect[lo:hi]) and calls[0][1] == hi - lo
+    mine = assign_shards(expect, world)[rank]      # cost-balanced (n(n-1), LPT): the same on every rank
+    ok = len(calls) == 1 and torch.equal(calls[0][0], expect[mine]) and calls[0][1] == mine.numel()
+    ok = ok and not torch.equal(mine, torch.arange(*shard_range(n_samples, rank, world)))
     ok = ok and [m.GetNumAtoms() for m in mols] == [int(v) for v in expect.tolist() if v % 2 == 0]
     ok = ok and all(float(m.coords[0, 0]) == m.GetNumAtoms() for m in mols)
     ok = ok and abs(gen.last_valid_fraction - float((expect % 2 == 0).float().mean())) < 1e-6
     # the generic entry: per-rank noise seeds and an EMPTY shard (1 sample, 2 ranks)
     seeds = []
-    _, full = sharded_generate(1, lambda: draw_global_sizes(1, 20, 20), lambda sz, lo_, hi_: {"v": sz.float()},
-                               seed=7, seed_fn=seeds.append)
+    _, full, shards = sharded_generate(1, lambda: draw_global_sizes(1, 20, 20), lambda sz, idx: {"v": sz.float()},
+                                       seed=7, seed_fn=seeds.append)
+    ok = ok and [ix.tolist() for ix in shards] == [[0], []]
     ok = ok and seeds == [rank_seed(7, rank)] and full["v"].tolist() == [20.0]
     # DEFAULT arguments (seed=None): the ranks must still draw DIFFERENT noise - base seed from rank 0 + rank
     seen = [None] * world
@@ -152,8 +185,7 @@ def _rank0_gather_worker(rank, world, port, n_samples, q):
                                            n_samples=n_samples, gather="rank0")
     torch.manual_seed(1000)
     expect = torch.randint(15, 40, (n_samples,))
-    lo, hi = shard_range(n_samples, rank, world)
-    mine = expect if rank == 0 else expect[lo:hi]          # rank 0: the whole batch; the others: their own shard only
+    mine = expect if rank == 0 else expect[assign_shards(expect, world)[rank]]   # rank 0: the whole batch; the others: their own shard only
     ok = [m.GetNumAtoms() for m in mols] == [int(v) for v in mine.tolist() if v % 2 == 0]
     ok = ok and gen.last_host_assembly_ms is not None and gen.last_host_assembly_ms < 1000.0
     try:

@@ -1101,6 +1101,57 @@ def test_generator_uses_an_injected_atom_order_provider(edm_sd, gcn_sd):
     assert torch.equal(res2["x"], gen2.last_batch["x"])
 
 
+def test_generator_pipelines_pooled_host_stages_like_the_serial_path(edm_sd, gcn_sd):
+    """f2 (round 5): the two host stages around the GCN - order + connectivity before it, the finish behind it - fanned
+    out over `host_pool` worker processes and pipelined per group of molecules (`_generate_shard`), with fake chunk
+    functions standing in for RDKit (tests/fake_host_tasks.py).  Pooled (4 workers), serial (0) and a ONE-launch
+    hand-off + GCN over the whole batch with the same decisions must agree bit for bit; molecule 1 cannot be "built" and
+    is dropped; the finish sees the records in the provider's order."""
+    import os
+    import numpy as np
+    from ml_conformer_generator_amd import MLConformerGenerator
+    from ml_conformer_generator_amd import host_pool as HP
+    from ml_conformer_generator_amd import rdkit_order as RO
+    from ml_conformer_generator_amd.handoff import bond_writeback_hip, prepare_adj_mat_seer_input_hip
+    fake = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_host_tasks.py")
+    ctx = torch.tensor([53.6424, 108.3042, 151.4399])
+    runs = {}
+    for workers in (0, 4):
+        gen = MLConformerGenerator(diffusion_steps=4, device=DEV, edm_weights=edm_sd, adj_mat_seer_weights=gcn_sd,
+                                   atom_order_provider=HP.TaskRef(fake, "order_chunk_no_sleep"),
+                                   finisher=HP.TaskRef(fake, "finish_chunk"), n_host_workers=workers)
+        torch.manual_seed(11); torch.cuda.manual_seed(11)
+        kept = gen.generate_conformers(reference_context=ctx, n_atoms=17, variance=2, n_samples=40, optimise_geometry=False)
+        assert gen.last_host_order_ms is not None and gen.last_host_finish_ms is not None
+        runs[workers] = (kept, {k: v.clone() for k, v in gen.last_batch.items()}, gen.last_order, gen.last_valid_fraction)
+    (k0, b0, o0, f0), (k4, b4, o4, f4) = runs[0], runs[4]
+    assert k0 == k4 and o0 == o4 and f0 == f4 and len(k0) > 0
+    for key in b0:
+        assert torch.equal(b0[key], b4[key]), key
+    assert all(r["mmff"] is False for r in k4)
+    # the four group launches against ONE launch over the whole batch with the same decisions
+    x, h, n_nodes = b4["x"], b4["h"], b4["n_nodes"]
+    order, conn, built = RO.batch_order_and_connectivity(HP.TaskRef(fake, "order_chunk_no_sleep"), x, h, n_nodes)
+    assert order == o4 and all(built)
+    el, dm, am, xo = prepare_adj_mat_seer_input_hip(x, h, n_nodes, order=order, connectivity=conn, with_coords=True)
+    bond = gen.adj_mat_seer.bond_orders(el, dm, am)
+    assert torch.equal(el, b4["elements"]) and torch.equal(bond, b4["bond"]) and torch.equal(xo, b4["x_ordered"])
+    # what the finish saw: atoms in the provider's order, fp32 coordinates as "%.9f" text would print them
+    sym, _ = bond_writeback_hip(bond, el, n_nodes)
+    zt = torch.tensor([6, 7, 8, 9, 15, 16, 17, 35])
+    done = 0
+    for b in range(40):
+        n = int(n_nodes[b])
+        nb = int((sym[b, :n, :n].cpu().tril(-1) != 0).sum())
+        if nb == 0:
+            continue
+        r = k4[done]; done += 1
+        z_gen = zt[h[b, :n].argmax(1).cpu()].tolist()
+        assert list(r["z"]) == [z_gen[i] for i in order[b]] and r["bonds"] == nb
+        assert r["xyz"] == "%.9f" % float(np.asarray(xo[b, :n].cpu().tolist(), dtype=np.float64).sum())
+    assert done == len(k4)
+
+
 def test_bond_writeback_kernel_vs_oracle():
     """f2: mcg_bond_writeback (lower-triangle bond write-back of mol_utils.py:210-211 + the validity substitute)
     against the oracle's plain-loop restatement, bit-exact, on chains with random extra bonds, broken chains
