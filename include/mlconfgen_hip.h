@@ -180,8 +180,11 @@ int mcg_gcn_check(mcg_gcn* g);
 /* EDM -> GCN hand-off (replaces samples_to_rdkit_mol + prepare_adj_mat_seer_input, utils/mol_utils.py:18-57,146-194,
  * for the tensor part): elements[B,42] int64 (atomic numbers, 0 padded), dist_mat[B,42,42] (distances + I),
  * adj_mat[B,42,42] ({0,1} covalent-radius connectivity + I) from x[B,N,3], h[B,N,8] one-hot and n_nodes[B] (device
- * int32).  Atoms keep their generation order. */
-int mcg_handoff(const float* x, const float* h, const int32_t* n_nodes_dev, int B, int N, float cov_factor,
+ * int32).  Atoms keep their generation order.  dist_mat is the reference's BIT FOR BIT: coordinates through the "%.9f" text
+ * round trip (rint(x * 1e9) / 1e9, exact in fp64), fp64 differences / sum / sqrt in `distance_matrix`'s order, ONE rounding
+ * to fp32 at the store (utils/mol_utils.py:46-51,129-143,168,176-187); the covalent rule compares in fp64 as well
+ * (ABI 4: cov_factor is a double). */
+int mcg_handoff(const float* x, const float* h, const int32_t* n_nodes_dev, int B, int N, double cov_factor,
                 int64_t* elements, float* dist_mat, float* adj_mat, void* stream);
 /* The same with the two RDKit-owned decisions of the reference open to the caller (`canonicalise`,
  * utils/mol_utils.py:110-126: DetermineConnectivity + `_smilesAtomOutputOrder` + RenumberAtoms; the MolGraph adjacency
@@ -199,7 +202,7 @@ int mcg_handoff(const float* x, const float* h, const int32_t* n_nodes_dev, int 
  *                molecules follow (conformer_generator.py:357-366);
  *   bad_order_flag (device int32, NULL = not wanted): set to 1 if an order entry was out of range; never cleared here.
  * elements / dist_mat / adj_mat come out in the permuted order. */
-int mcg_handoff_ex(const float* x, const float* h, const int32_t* n_nodes_dev, int B, int N, float cov_factor,
+int mcg_handoff_ex(const float* x, const float* h, const int32_t* n_nodes_dev, int B, int N, double cov_factor,
                    const int32_t* order, const uint8_t* conn_in, int64_t* elements, float* dist_mat, float* adj_mat,
                    float* x_out, int32_t* bad_order_flag, void* stream);
 

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MCG_LIB_PATH: measurement builds only (tools/build_variants.sh: ablation / experiment variants of the same library)
 LIB_PATH = os.environ.get("MCG_LIB_PATH") or os.path.join(_HERE, "libmlconfgen_hip.so")
 
-_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+_vp, _i, _f, _d = C.c_void_p, C.c_int, C.c_float, C.c_double
 _pp = C.POINTER(C.c_void_p)
 
 # name -> (restype, argtypes); mirrors include/mlconfgen_hip.h one to one
@@ -49,8 +49,8 @@ SIGNATURES: Dict[str, tuple] = {
     "mcg_gcn_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "mcg_gcn_check": (_i, [_vp]),
     "mcg_shape_tanimoto": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp]),
-    "mcg_handoff": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
-    "mcg_handoff_ex": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mcg_handoff": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp]),
+    "mcg_handoff_ex": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mcg_bond_writeback": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "mcg_ifm_merge": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
 }

@@ -6,3 +6,6 @@
 int mcg_plan_B(const mcg_plan* p);
 int mcg_plan_N(const mcg_plan* p);
 const int* mcg_plan_n_nodes(const mcg_plan* p);   // device pointer
+// "everything enqueued on this plan so far" -> the plan's completion event, recorded on the caller's stream
+// (mcg_plan_destroy waits for it before the plan's blocks return to the pool)
+void mcg_plan_mark_done(const mcg_plan* p, void* stream);

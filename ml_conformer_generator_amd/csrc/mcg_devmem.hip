@@ -76,8 +76,8 @@ int mcg_dev_alloc(size_t bytes, void** out) {
     return MCG_OK;
 }
 
-// The caller guarantees that no kernel still uses the block (mcg_plan_destroy synchronises the device first - what the
-// hipFree it replaces did implicitly).
+// The caller guarantees that no kernel still uses the block (mcg_plan_destroy waits for the plan's completion event on the
+// plan's own device first - what the hipFree it replaces did implicitly).
 void mcg_dev_free(void* p) {
     if (!p) return;
     const int dev = cur_dev();
@@ -85,12 +85,16 @@ void mcg_dev_free(void* p) {
     {
         std::lock_guard<std::mutex> lk(g_mu);
         DevPool* P = &g_pools[dev];
+        bool found = false;
         auto it = P->live.find(p);
-        if (it == P->live.end()) {                         // allocated while another device was current: look it up
-            for (DevPool& Q : g_pools) { it = Q.live.find(p); if (it != Q.live.end()) { P = &Q; break; } }
-            if (it == P->live.end()) { release = true; }
-        }
-        if (!release) {
+        if (it != P->live.end()) found = true;
+        else                                               // allocated while another device was current: look it up
+            for (DevPool& Q : g_pools) {
+                auto jt = Q.live.find(p);
+                if (jt != Q.live.end()) { P = &Q; it = jt; found = true; break; }      // (iterators of ONE map only)
+            }
+        if (!found) release = true;                        // not one of ours: back to the driver
+        else {
             const size_t cls = it->second;
             P->live.erase(it);
             P->in_use -= cls;

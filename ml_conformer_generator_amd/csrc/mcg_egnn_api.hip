@@ -393,9 +393,19 @@ static int dynamics_launch(const mcg_egnn* m, mcg_plan* pl, const float* t, cons
 }
 
 // out[B,N,11] = EGNNDynamics.forward(t[B], xh[B,N,11], node_mask==prefix(n_nodes), context[B,N,3])
+static int dynamics_entry(const mcg_egnn* m, mcg_plan* pl, const float* t, const float* xh, const float* context,
+                          float* out, void* stream);
+
 int mcg_egnn_dynamics(const mcg_egnn* m, mcg_plan* pl, const float* t, const float* xh, const float* context,
                       float* out, void* stream) {
     if (!m || !pl || !t || !xh || !context || !out) { mcg_set_error("mcg_egnn_dynamics: null argument"); return MCG_ERR_ARG; }
+    const int rc = dynamics_entry(m, pl, t, xh, context, out, stream);
+    mcg_plan_mark(pl, (hipStream_t)stream);          // also after a failure: some launches may be in flight
+    return rc;
+}
+
+static int dynamics_entry(const mcg_egnn* m, mcg_plan* pl, const float* t, const float* xh, const float* context,
+                          float* out, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     static int use_graph = -1;
     if (use_graph < 0) { const char* e = getenv("MCG_GRAPH"); use_graph = (e && atoi(e) == 0) ? 0 : 1; }
@@ -425,7 +435,7 @@ int mcg_egnn_dynamics(const mcg_egnn* m, mcg_plan* pl, const float* t, const flo
             pl->allocs.push_back(st);
             pl->xh_stage = st; pl->out_stage = st + n_xh; pl->ctx_stage = st + 2 * n_xh;
             if (getenv("MCG_VERBOSE")) fprintf(stderr, "[mcg] caller tensors move between calls: graph on staging buffers\n");
-            return mcg_egnn_dynamics(m, pl, t, xh, context, out, stream);
+            return dynamics_entry(m, pl, t, xh, context, out, stream);
         }
         (void)hipGetLastError();
     }
@@ -461,6 +471,7 @@ int mcg_egnn_dynamics(const mcg_egnn* m, mcg_plan* pl, const float* t, const flo
 // current state (bench.py brackets this with events on the same stream for the roofline figure).
 int mcg_bench_edge(const mcg_egnn* m, mcg_plan* pl, int layer, int equiv, int iters, void* stream) {
     if (!m || !pl || iters < 1 || layer < 0 || layer >= (equiv ? m->n_blocks : 2 * m->n_blocks)) return MCG_ERR_ARG;
+    mcg_plan_mark_guard done{pl, (hipStream_t)stream};
     for (int i = 0; i < iters; ++i)
         if (int e = run_edge(pl, equiv ? m->equiv[layer] : m->gcl_edge[layer], equiv != 0, equiv ? pl->Px : pl->P,
                              (hipStream_t)stream, m->bf16, m->x6, edge_wgc(m, pl))) return e;
@@ -471,6 +482,7 @@ int mcg_egnn_gcl_debug(const mcg_egnn* m, mcg_plan* pl, int layer, const float* 
                        const float* x0, void* stream) {
     if (!m || !pl || layer < 0 || layer >= 2 * m->n_blocks) return MCG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    mcg_plan_mark_guard done{pl, s};
     MCG_HIP(hipMemsetAsync(pl->h, 0, (size_t)pl->M * HP * sizeof(float), s));
     MCG_HIP(hipMemsetAsync(pl->x, 0, (size_t)pl->M * 4 * sizeof(float), s));
     MCG_HIP(hipMemsetAsync(pl->x0, 0, (size_t)pl->M * 4 * sizeof(float), s));
@@ -489,6 +501,7 @@ int mcg_bench_edge_incall(const mcg_egnn* m, mcg_plan* pl, const float* t, const
                           int calls, float* us_host /*[4]*/, void* stream) {
     if (!m || !pl || !t || !xh || !context || !out || !us_host || calls < 1) return MCG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    mcg_plan_mark_guard done{pl, s};
     // event pairs are created up front: nothing but launches between the kernels of a call (the GPU must not idle between
     // them - it clocks down within microseconds and the next kernel would be timed on the ramp)
     const size_t n_ranges = pl->subs.empty() ? 1 : pl->subs.size();
@@ -534,6 +547,7 @@ int mcg_egnn_block_debug(const mcg_egnn* m, mcg_plan* pl, int block, float* h_io
                          void* stream) {
     if (!m || !pl || block < 0 || block >= m->n_blocks) return MCG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    mcg_plan_mark_guard done{pl, s};
     MCG_HIP(hipMemsetAsync(pl->h, 0, (size_t)pl->M * HP * sizeof(float), s));
     MCG_HIP(hipMemsetAsync(pl->x, 0, (size_t)pl->M * 4 * sizeof(float), s));
     MCG_HIP(hipMemsetAsync(pl->x0, 0, (size_t)pl->M * 4 * sizeof(float), s));

@@ -129,6 +129,13 @@ struct mcg_plan {
     const int4* pending_slots = nullptr;
     std::vector<void*> allocs;              // blocks of the plan pool (mcg_dev_alloc)
     bool is_sub = false;                    // a molecule range of another plan
+    // destruction: the plan's blocks go back to a pool, so everything launched on them must have finished - every entry
+    // point that enqueues work on this plan records `ev_done` on the caller's stream behind it (mcg_plan_mark; the molecule
+    // ranges' streams have joined that stream by then) and mcg_plan_destroy waits for THAT event on the plan's OWN device,
+    // instead of stalling the whole (current) device
+    int dev = -1;                           // device the plan lives on (current device of mcg_plan_create)
+    hipEvent_t ev_done = nullptr;
+    mutable bool ev_pending = false;
     // optional split into independent molecule ranges that run on separate HIP streams
     // (the latency-bound node GEMMs of one range overlap the edge kernels of the other)
     std::vector<mcg_plan*> subs;
@@ -154,6 +161,17 @@ struct mcg_plan {
     struct EdgeTiming { hipEvent_t t0, t1; bool equiv, used; };
     std::vector<EdgeTiming>* edge_timing = nullptr;       // pool of pre-created event pairs (no API call between launches)
     size_t* edge_timing_next = nullptr;                   // shared cursor into the pool
+};
+
+// records "everything enqueued on this plan so far" on the caller's stream (see mcg_plan::ev_done)
+inline void mcg_plan_mark(const mcg_plan* pl, hipStream_t s) {
+    if (pl && pl->ev_done && hipEventRecord(pl->ev_done, s) == hipSuccess) pl->ev_pending = true;
+    else (void)hipGetLastError();
+}
+
+struct mcg_plan_mark_guard {              // marks at scope exit, whatever the return path
+    const mcg_plan* p; hipStream_t s;
+    ~mcg_plan_mark_guard() { mcg_plan_mark(p, s); }
 };
 
 // device-memory pool of the plans (mcg_devmem.hip): blocks of destroyed plans are reused by new ones

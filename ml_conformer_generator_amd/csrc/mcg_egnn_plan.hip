@@ -7,6 +7,7 @@
 
 namespace { constexpr int HP = MCG_HP; }
 
+void mcg_plan_mark_done(const mcg_plan* p, void* stream) { mcg_plan_mark(p, (hipStream_t)stream); }
 int mcg_plan_B(const mcg_plan* p) { return p->B; }
 int mcg_plan_N(const mcg_plan* p) { return p->N; }
 const int* mcg_plan_n_nodes(const mcg_plan* p) { return p->n_nodes; }
@@ -120,8 +121,20 @@ extern "C" {
 void mcg_plan_destroy(mcg_plan* p) {
     if (!p) return;
     // the blocks go back to the plan pool, not to the driver: nothing may still be running on them when another plan can
-    // take them (hipFree used to wait implicitly).  Once, up front, before the molecule ranges hand back theirs.
-    if (!p->is_sub && !p->allocs.empty()) (void)hipDeviceSynchronize();
+    // take them (hipFree used to wait implicitly).  Once, up front, before the molecule ranges hand back theirs: on the
+    // plan's OWN device (the caller's current device may be another one - a generator on cuda:1, a GC thread), and only for
+    // the plan's own last launch (ev_done, recorded behind every entry point), not for the whole device.
+    int prev_dev = -1;
+    if (!p->is_sub) {
+        if (hipGetDevice(&prev_dev) != hipSuccess) { (void)hipGetLastError(); prev_dev = -1; }
+        if (p->dev >= 0 && prev_dev != p->dev && hipSetDevice(p->dev) != hipSuccess) (void)hipGetLastError();
+        if (p->ev_done) {
+            if (p->ev_pending && hipEventSynchronize(p->ev_done) != hipSuccess) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }
+        } else if (!p->allocs.empty()) {
+            (void)hipDeviceSynchronize();           // a plan that never got its event (failed half-way through creation)
+        }
+        for (hipStream_t st : p->streams) (void)hipStreamSynchronize(st);       // joined behind ev_done already: returns at once
+    }
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     for (mcg_plan* q : p->subs) mcg_plan_destroy(q);
@@ -129,7 +142,10 @@ void mcg_plan_destroy(mcg_plan* p) {
     for (hipEvent_t e : p->ev_join) (void)hipEventDestroy(e);
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     for (void* q : p->allocs) mcg_dev_free(q);
+    if (p->ev_done) (void)hipEventDestroy(p->ev_done);
+    const bool restore = !p->is_sub && prev_dev >= 0 && prev_dev != p->dev;
     delete p;
+    if (restore && hipSetDevice(prev_dev) != hipSuccess) (void)hipGetLastError();
 }
 
 static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, const mcg_plan_opts* opts);
@@ -148,6 +164,8 @@ int mcg_plan_create_ex(int B, int N, const int32_t* n_nodes_host, const mcg_plan
             if (opts->reserved[k] != 0) { mcg_set_error("mcg_plan_create_ex: mcg_plan_opts.reserved must be zero"); return MCG_ERR_ARG; }
     mcg_plan* p = nullptr;
     if (int e = plan_create_single(B, N, n_nodes_host, opts, &p)) return e;
+    if (hipGetDevice(&p->dev) != hipSuccess) { (void)hipGetLastError(); p->dev = -1; }
+    if (hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); p->ev_done = nullptr; }
     if (int e = plan_finish(p, B, N, n_nodes_host, opts)) {
         mcg_plan_destroy(p);          // streams, events, sub-plans and buffers created so far
         return e;
@@ -216,6 +234,7 @@ int mcg_plan_info(const mcg_plan* p, int32_t* info /*[8]*/) {
 // 3 t1[M][432], 4 x[M][4]
 int mcg_plan_peek(const mcg_plan* pl, int which, float* dst, void* stream) {
     if (!pl || !dst) return MCG_ERR_ARG;
+    mcg_plan_mark_guard done{pl, (hipStream_t)stream};
     const float* src = nullptr; size_t n = 0;
     switch (which) {
         case 0: src = pl->h; n = (size_t)pl->M * HP; break;

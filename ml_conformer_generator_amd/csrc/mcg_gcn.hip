@@ -109,22 +109,32 @@ __global__ __launch_bounds__(256) void k_symm(const float* __restrict__ res, flo
 // un-renumbered molecule (:117); it is permuted like the atoms.  NULL = the covalent-radius rule.
 // `x_out` (may be NULL): the coordinates in the order of the GCN input (the reference's `canonicalised_samples`).
 // `bad` (may be NULL): set to 1 when an order entry is outside [0, n) (the entry is clamped).
+// Distances are the reference's, bit for bit: its coordinates make a trip through XYZ text written with "%.9f"
+// (mol_utils.py:46-51) and come back as DOUBLES (`torch.tensor(conf.GetPositions())`, :168), `distance_matrix` (:129-143)
+// is fp64 - sqrt((dx^2 + dy^2) + dz^2), torch.sum's order over 3 elements - and the result is rounded ONCE, when it is stored
+// into the fp32 batch tensor (:178-187).  The text round trip of a float x is rint(x * 1e9) / 1e9 in fp64, exactly:
+// 1e9 = 2^9 * 5^9 has a 21-bit odd part, so the product with a 24-bit float is exact in fp64 (|x| < 8e6), rint is
+// printf's round-half-even on the exact binary value, and the correctly rounded quotient k / 1e9 is the double strtod
+// returns for the decimal k * 1e-9.  No FMA contraction anywhere in this arithmetic.
+__device__ __forceinline__ double text_round_trip_9(float v) { return __ddiv_rn(rint(__dmul_rn((double)v, 1e9)), 1e9); }
+
 __global__ __launch_bounds__(256) void k_handoff(const float* __restrict__ x, const float* __restrict__ h,
-                                                  const int* __restrict__ n_nodes, int N, float cov_factor,
+                                                  const int* __restrict__ n_nodes, int N, double cov_factor,
                                                   const int* __restrict__ order, const uint8_t* __restrict__ conn_in,
                                                   int64_t* __restrict__ elements, float* __restrict__ dist,
                                                   float* __restrict__ adj, float* __restrict__ x_out,
                                                   int* __restrict__ bad) {
-    __shared__ float sx[D][3];
-    __shared__ float srad[D];
+    __shared__ double sx[D][3];      // coordinates as the GCN input's Mol holds them (after the "%.9f" text)
+    __shared__ float sxf[D][3];      // the generated fp32 coordinates (x_out)
+    __shared__ double srad[D];
     __shared__ int ssrc[D];
     const int b = blockIdx.x;
     const int n = min(n_nodes[b], min(D, N));
     // class -> atomic number (config.py:20-29) and single-bond covalent radius (Cordero 2008)
     const int zt[8] = {6, 7, 8, 9, 15, 16, 17, 35};
-    const float rt[8] = {0.76f, 0.71f, 0.66f, 0.57f, 1.07f, 1.05f, 1.02f, 1.20f};
+    const double rt[8] = {0.76, 0.71, 0.66, 0.57, 1.07, 1.05, 1.02, 1.20};
     for (int i = threadIdx.x; i < D; i += 256) {
-        int z = 0; float r = 0.f; float px = 0.f, py = 0.f, pz = 0.f; int src = i;
+        int z = 0; double r = 0.0; float px = 0.f, py = 0.f, pz = 0.f; int src = i;
         if (i < n) {
             if (order) {
                 src = order[(size_t)b * D + i];
@@ -138,28 +148,30 @@ __global__ __launch_bounds__(256) void k_handoff(const float* __restrict__ x, co
             const float* xr = x + ((size_t)b * N + src) * 3;
             px = xr[0]; py = xr[1]; pz = xr[2];
         }
-        srad[i] = r; sx[i][0] = px; sx[i][1] = py; sx[i][2] = pz; ssrc[i] = src;
+        srad[i] = r; ssrc[i] = src;
+        sxf[i][0] = px; sxf[i][1] = py; sxf[i][2] = pz;
+        sx[i][0] = text_round_trip_9(px); sx[i][1] = text_round_trip_9(py); sx[i][2] = text_round_trip_9(pz);
         elements[(size_t)b * D + i] = z;
     }
     __syncthreads();
     if (x_out)
         for (int i = threadIdx.x; i < N * 3; i += 256) {
             const int a = i / 3;
-            x_out[(size_t)b * N * 3 + i] = a < n ? sx[a][i - a * 3] : 0.f;
+            x_out[(size_t)b * N * 3 + i] = a < n ? sxf[a][i - a * 3] : 0.f;
         }
     for (int idx = threadIdx.x; idx < D * D; idx += 256) {
         const int i = idx / D, j = idx - i * D;
-        float d = 0.f, a = 0.f;
+        double d = 0.0; float a = 0.f;
         if (i < n && j < n) {
-            const float dx = sx[i][0] - sx[j][0], dy = sx[i][1] - sx[j][1], dz = sx[i][2] - sx[j][2];
-            d = sqrtf(dx * dx + dy * dy + dz * dz);
+            const double dx = __dsub_rn(sx[i][0], sx[j][0]), dy = __dsub_rn(sx[i][1], sx[j][1]), dz = __dsub_rn(sx[i][2], sx[j][2]);
+            d = __dsqrt_rn(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz)));
             if (i != j) {
                 if (conn_in) a = conn_in[(size_t)b * D * D + ssrc[i] * D + ssrc[j]] ? 1.f : 0.f;
-                else if (d < cov_factor * (srad[i] + srad[j])) a = 1.f;
+                else if (d < __dmul_rn(cov_factor, __dadd_rn(srad[i], srad[j]))) a = 1.f;
             }
         }
-        if (i == j) { d += 1.f; a = 1.f; }            // + I on the full 42-diagonal (mol_utils.py:175-187)
-        dist[(size_t)b * D * D + idx] = d;
+        if (i == j) { d = __dadd_rn(d, 1.0); a = 1.f; }   // + I on the full 42-diagonal (mol_utils.py:175-187), still fp64
+        dist[(size_t)b * D * D + idx] = (float)d;          // the ONE rounding: fp64 -> the fp32 batch tensor
         adj[(size_t)b * D * D + idx] = a;
     }
 }
@@ -318,7 +330,7 @@ int mcg_gcn_forward(mcg_gcn* g, const int64_t* elements, const float* dist_mat, 
 }
 
 // elements[B,42] i64, dist_mat[B,42,42], adj_mat[B,42,42] from sampler outputs x[B,N,3], h[B,N,8] (one-hot)
-int mcg_handoff_ex(const float* x, const float* h, const int32_t* n_nodes_dev, int B, int N, float cov_factor,
+int mcg_handoff_ex(const float* x, const float* h, const int32_t* n_nodes_dev, int B, int N, double cov_factor,
                    const int32_t* order, const uint8_t* conn_in, int64_t* elements, float* dist_mat, float* adj_mat,
                    float* x_out, int32_t* bad_order_flag, void* stream) {
     if (!x || !h || !n_nodes_dev || !elements || !dist_mat || !adj_mat || B < 1 || N < 1) {
@@ -332,7 +344,7 @@ int mcg_handoff_ex(const float* x, const float* h, const int32_t* n_nodes_dev, i
     return MCG_OK;
 }
 
-int mcg_handoff(const float* x, const float* h, const int32_t* n_nodes_dev, int B, int N, float cov_factor,
+int mcg_handoff(const float* x, const float* h, const int32_t* n_nodes_dev, int B, int N, double cov_factor,
                 int64_t* elements, float* dist_mat, float* adj_mat, void* stream) {
     return mcg_handoff_ex(x, h, n_nodes_dev, B, N, cov_factor, nullptr, nullptr, elements, dist_mat, adj_mat, nullptr, nullptr,
                           stream);

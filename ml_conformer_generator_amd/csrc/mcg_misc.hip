@@ -19,7 +19,7 @@ extern "C" void mcg_set_error(const char* fmt, ...) {
 
 extern "C" const char* mcg_last_error(void) { return g_err; }
 
-extern "C" int mcg_abi_version(void) { return 3; }      // 2: mcg_plan_opts / mcg_plan_create_ex / mcg_egnn_set_option; 3: mcg_handoff_ex
+extern "C" int mcg_abi_version(void) { return 4; }      // 2: mcg_plan_opts / mcg_plan_create_ex / mcg_egnn_set_option; 3: mcg_handoff_ex; 4: cov_factor is a double (fp64 hand-off distances)
 
 // launch-shape counters of the GEMM launchers (mcg_gemm.h); relaxed atomics: a measurement hook, not a synchronisation point
 static std::atomic<int64_t> g_gemm_launches[4][8];

@@ -189,6 +189,7 @@ int mcg_sampler_noise(const mcg_plan* pl, const float* randn_x, const float* ran
     hipLaunchKernelGGL(k_noise, dim3(mcg_plan_B(pl)), dim3(64), 0, (hipStream_t)stream, randn_x, randn_h,
                        mcg_plan_n_nodes(pl), mcg_plan_N(pl), eps);
     MCG_HIP(hipGetLastError());
+    mcg_plan_mark_done(pl, stream);
     return MCG_OK;
 }
 
@@ -200,6 +201,7 @@ int mcg_sampler_step(const mcg_egnn* m, mcg_plan* pl, float* z, const float* con
     hipLaunchKernelGGL(k_step, dim3(mcg_plan_B(pl)), dim3(64), 0, (hipStream_t)stream, z, eps_hat_scratch, randn_x,
                        randn_h, mcg_plan_n_nodes(pl), mcg_plan_N(pl), alpha_ts, c_eps, c_noise);
     MCG_HIP(hipGetLastError());
+    mcg_plan_mark_done(pl, stream);
     return MCG_OK;
 }
 
@@ -211,6 +213,7 @@ int mcg_sampler_decode(const mcg_egnn* m, mcg_plan* pl, const float* z0, const f
     hipLaunchKernelGGL(k_decode, dim3(mcg_plan_B(pl)), dim3(64), 0, (hipStream_t)stream, z0, eps_hat_scratch, randn_x,
                        mcg_plan_n_nodes(pl), mcg_plan_N(pl), inv_alpha0, sigma0, sigma_x, norm_x, norm_h, x_out, h_out);
     MCG_HIP(hipGetLastError());
+    mcg_plan_mark_done(pl, stream);
     return MCG_OK;
 }
 
@@ -220,6 +223,7 @@ int mcg_sampler_blend(const mcg_plan* pl, float* z, const float* z_known, const 
     hipLaunchKernelGGL(k_blend, dim3(mcg_plan_B(pl)), dim3(64), 0, (hipStream_t)stream, z, z_known, fixed_mask, randn_x,
                        randn_h, mcg_plan_n_nodes(pl), mcg_plan_N(pl), alpha_s, sigma_s, blend, mode);
     MCG_HIP(hipGetLastError());
+    mcg_plan_mark_done(pl, stream);
     return MCG_OK;
 }
 

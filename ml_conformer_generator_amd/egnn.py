@@ -102,6 +102,7 @@ class EGNNDynamics(torch.nn.Module):
         self._plans: Dict[tuple, BatchPlan] = {}      # LRU (dict order = recency), `plan_cache_size` entries
         self.plan_cache_size = 8
         self._edge_mask_ok = None          # (weakref to the last verified edge_mask tensor, its version, its plan)
+        self._node_mask_ok = None          # (weakref to the last verified node_mask tensor, its version, its sizes)
 
     # -- weights ------------------------------------------------------------------
     def load_reference_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "dynamics.egnn.") -> None:
@@ -178,7 +179,33 @@ class EGNNDynamics(torch.nn.Module):
         self._plans[key] = p
         return p
 
-    def check_edge_mask(self, plan: BatchPlan, edge_mask) -> None:
+    def sizes_for(self, node_mask: torch.Tensor) -> torch.Tensor:
+        """n_nodes[B] (CPU int32) of a prefix node mask WITHOUT a device compare + host sync where the verdict is already
+        known: masks built by this package carry their sizes (`mol_utils.tag_canonical_masks`), and the last externally
+        built mask is remembered by tensor identity + version counter - the reference's own sampler loop passes the same
+        `node_mask` tensor to `dynamics` on every step (equivariant_diffusion.py:187) and pays the check once."""
+        tag = getattr(node_mask, "_mcg_mask_tag", None)
+        if tag is not None and tag[1] == node_mask._version:
+            return tag[2]
+        hit = self._node_mask_ok
+        if hit is not None and hit[0]() is node_mask and hit[1] == node_mask._version:
+            return hit[2]
+        sizes = sizes_from_node_mask(node_mask)
+        self._node_mask_ok = (weakref.ref(node_mask), node_mask._version, sizes)
+        return sizes
+
+    def release_cached_memory(self) -> dict:
+        """Drop what this object and the library cache on the device: the LRU plan cache (their graphs, tables and
+        workspaces) and the free blocks of the library's plan pool (up to 4 GiB per device that PyTorch's caching allocator
+        cannot see - call this from an out-of-memory retry path).  Returns the pool's counters after the trim."""
+        self._plans.clear()
+        self._edge_mask_ok = self._node_mask_ok = None
+        stats = torch.zeros(4, dtype=torch.int64)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mcg_pool_stats(stats.data_ptr(), 1), "mcg_pool_stats")
+        return dict(zip(("in_use_bytes", "cached_bytes", "driver_allocs", "pool_hits"), (int(v) for v in stats)))
+
+    def check_edge_mask(self, plan: BatchPlan, edge_mask, node_mask=None) -> None:
         """The reference multiplies every message by whatever `edge_mask` the caller passes (egnn.py:477-478,51,127); the
         HIP kernels implement exactly one - the canonical mask of the plan's prefix node mask.  Any other mask is REFUSED
         (ValueError) instead of being silently ignored.  One device compare + sync per distinct mask tensor: the verdict is
@@ -186,6 +213,10 @@ class EGNNDynamics(torch.nn.Module):
         pays it once."""
         if edge_mask is None:
             return
+        tag, ntag = getattr(edge_mask, "_mcg_mask_tag", None), getattr(node_mask, "_mcg_mask_tag", None)
+        if (tag is not None and ntag is not None and tag[0] is ntag[0] and tag[1] == edge_mask._version
+                and ntag[1] == node_mask._version):
+            return                          # built together by prepare_masks, untouched since: canonical by construction
         hit = self._edge_mask_ok
         if hit is not None and hit[0]() is edge_mask and hit[1] == edge_mask._version and hit[2]() is plan:
             return
@@ -213,8 +244,8 @@ class EGNNDynamics(torch.nn.Module):
         `node_mask` (it is fully determined by it in every caller of the reference); anything else raises ValueError
         (`check_edge_mask`).  None skips the check."""
         B, N, _ = xh.shape
-        plan = self.plan(sizes_from_node_mask(node_mask), N)
-        self.check_edge_mask(plan, edge_mask)
+        plan = self.plan(self.sizes_for(node_mask), N)
+        self.check_edge_mask(plan, edge_mask, node_mask)
         f32 = dict(device=self.device, dtype=torch.float32)
         return self.run(plan, t.reshape(B).to(**f32).contiguous(), xh.to(**f32).contiguous(),
                         context.to(**f32).contiguous())

@@ -108,8 +108,8 @@ class EquivariantDiffusion(torch.nn.Module):
         def __init__(self, model: "EquivariantDiffusion", node_mask, context, edge_mask=None):
             dev = model.device
             self.B, self.N = int(node_mask.shape[0]), int(node_mask.shape[1])
-            self.plan: BatchPlan = model.dynamics.plan(sizes_from_node_mask(node_mask), self.N)
-            model.dynamics.check_edge_mask(self.plan, edge_mask)      # a non-canonical edge mask is refused, not ignored
+            self.plan: BatchPlan = model.dynamics.plan(model.dynamics.sizes_for(node_mask), self.N)
+            model.dynamics.check_edge_mask(self.plan, edge_mask, node_mask)      # a non-canonical edge mask is refused, not ignored
             # Latent, network output and context live in buffers owned by the (cached) plan: the denoiser call is a HIP
             # graph keyed by these addresses, so a second sampling run over the same batch shape replays the captured
             # graph instead of re-capturing it (or, from the third run on, paying three staging copies per call).

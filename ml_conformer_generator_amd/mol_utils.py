@@ -27,7 +27,18 @@ def prepare_masks(n_nodes: torch.Tensor, max_n_nodes: int, device) -> Tuple[torc
     edge_mask = node_mask.unsqueeze(1) * node_mask.unsqueeze(2)
     edge_mask = edge_mask * (1.0 - torch.eye(max_n_nodes)).unsqueeze(0)
     edge_mask = edge_mask.reshape(n.numel() * max_n_nodes * max_n_nodes, 1).to(device)
-    return node_mask.unsqueeze(2).to(device), edge_mask
+    node_mask = node_mask.unsqueeze(2).to(device)
+    tag_canonical_masks(node_mask, edge_mask, n)
+    return node_mask, edge_mask
+
+
+def tag_canonical_masks(node_mask: torch.Tensor, edge_mask: torch.Tensor, sizes: torch.Tensor) -> None:
+    """Masks built HERE are a prefix mask and its canonical edge mask by construction: say so on the tensor objects
+    (sizes, a shared token, the version counters at tagging time) so that `EGNNDynamics.sizes_for` / `check_edge_mask` need
+    no device compare + host sync for them - a later in-place edit bumps `_version` and voids the tag."""
+    token = object()
+    node_mask._mcg_mask_tag = (token, node_mask._version, sizes.to(torch.int32).reshape(-1).clone())
+    edge_mask._mcg_mask_tag = (token, edge_mask._version)
 
 
 def prepare_edm_input(n_samples: int, reference_context: torch.Tensor, context_norms: Dict[str, torch.Tensor],

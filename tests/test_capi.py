@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     h = _lib.lib()
     for s in declared_symbols():
         assert hasattr(h, s), s
-    assert h.mcg_abi_version() == 3
+    assert h.mcg_abi_version() == 4
     assert h.mcg_last_error() is not None
 
 

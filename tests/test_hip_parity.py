@@ -423,6 +423,40 @@ def test_non_canonical_edge_mask_is_refused_not_ignored(dyn, sampler_factory):
     assert bool(torch.isfinite(x).all())
 
 
+def test_mask_verdicts_are_cached_so_a_sampler_loop_pays_no_sync_per_call(dyn, monkeypatch):
+    """Round-4 review: `EGNNDynamics.forward` derived the sizes with a device compare + `.cpu()` on EVERY call - one host
+    sync per denoiser step for anyone who binds op seam 1 inside the reference's own sampler loop.  Now: once per mask
+    tensor (identity + version), never for masks built by this package's `prepare_masks` (tagged), and an in-place edit of
+    a checked or tagged mask is noticed."""
+    from ml_conformer_generator_amd import egnn as E
+    from ml_conformer_generator_amd.mol_utils import prepare_masks
+    g = load_golden("dynamics_b4n19.npz")
+    nm, xh, ctx, t = g["node_mask"].to(DEV), g["xh"].to(DEV), g["context"].to(DEV), g["t"].to(DEV)
+    em = edge_mask_of(g["node_mask"]).to(DEV)
+    calls = []
+    real = E.sizes_from_node_mask
+    monkeypatch.setattr(E, "sizes_from_node_mask", lambda m: (calls.append(1), real(m))[1])
+    ref = dyn(t, xh, nm, em, ctx)
+    for _ in range(5):                                           # the reference's loop: the same mask tensors every step
+        assert torch.equal(dyn(t, xh, nm, em, ctx), ref)
+    assert len(calls) == 1
+    sizes = g["node_mask"].sum(1).reshape(-1).long()
+    nm2, em2 = prepare_masks(sizes, nm.shape[1], DEV)            # the package's own masks: no check at all
+    plan = dyn.plan(dyn.sizes_for(nm2), nm.shape[1])
+    monkeypatch.setattr(plan, "edge_mask", lambda: (_ for _ in ()).throw(AssertionError("tagged masks need no device compare")))
+    assert torch.equal(dyn(t, xh, nm2, em2, ctx), ref) and len(calls) == 1
+    monkeypatch.undo()
+    em2[int(torch.nonzero(em2)[3, 0])] = 0.0                     # a tagged mask edited in place loses its tag
+    with pytest.raises(ValueError, match="canonical"):
+        dyn(t, xh, nm2, em2, ctx)
+    nm2[0, 0] = 0.0                                              # ... and so does a tagged node mask (no longer a prefix)
+    with pytest.raises(ValueError, match="prefix"):
+        dyn(t, xh, nm2, None, ctx)
+    stats = dyn.release_cached_memory()
+    assert stats["cached_bytes"] == 0 and len(dyn._plans) == 0
+    assert torch.equal(dyn(t, xh, nm, em, ctx), ref)             # everything is rebuilt on demand
+
+
 # (mode "f32x6": the opt-in split-operand kernels under the SAME per-step tolerance as the exact path - every golden
 #  trajectory of the reference: plain, resampling, inpainting, fragment merge)
 @pytest.mark.parametrize("mode", ["f32", "f32x6"])
@@ -915,8 +949,10 @@ def test_bf16_mode_vs_emulation_and_fp32(edm_sd):
 def test_handoff_kernel_vs_oracle():
     """f1: mcg_handoff against the ORACLE restatement of the tensor half of samples_to_rdkit_mol +
     prepare_adj_mat_seer_input (mol_utils.py:18-57,146-194; fp64 distances of the "%.9f" coordinates, + I, pad 42;
-    connectivity substitute + I).  Elements exact; distances to fp32 rounding of the fp64 result (rtol 1e-6);
-    adjacency exact except where a distance sits within rounding of its covalent threshold."""
+    connectivity substitute + I).  Round 5: the kernel computes what the reference computes - the "%.9f" text round trip of
+    the coordinate (exact in fp64), fp64 `distance_matrix`, ONE rounding to fp32 - so elements, distances AND the
+    covalent-rule adjacency are BIT-EXACT, no borderline carve-out.  Also against the reference's own `distance_matrix`
+    (fixture `handoff_tensor_half.npz`)."""
     from ml_conformer_generator_amd.handoff import prepare_adj_mat_seer_input_hip
     from oracle import host_oracle as HO
     torch.manual_seed(4)
@@ -929,22 +965,28 @@ def test_handoff_kernel_vs_oracle():
     el0, dm0, am0 = HO.adj_mat_seer_input(x, h, n_nodes)
     el1, dm1, am1 = prepare_adj_mat_seer_input_hip(x.to(DEV), h.to(DEV), n_nodes)
     assert torch.equal(el1.cpu(), el0)
-    assert torch.allclose(dm1.cpu(), dm0, rtol=1e-6, atol=1e-6)
-    rc = torch.zeros(36)
-    for z, r in HO._RCOV.items():
-        rc[z] = r
-    thr = 1.3 * (rc[el0].unsqueeze(1) + rc[el0].unsqueeze(2))
-    borderline = ((dm0 - thr).abs() < 1e-5) & (thr > 0)                # real pairs within rounding of their threshold
-    assert torch.equal(am1.cpu()[~borderline], am0[~borderline])
-    assert int(borderline.sum()) < 4
+    n_diff = int((dm1.cpu() != dm0).sum())
+    assert n_diff == 0, f"{n_diff} of {dm0.numel()} distances differ from the fp64 -> fp32 reference arithmetic"
+    assert torch.equal(am1.cpu(), am0)
     assert int(am0.sum()) > B * 42                                   # some bonds were actually perceived
+    # coordinates at other magnitudes (the "%.9f" rounding acts on the 9th DECIMAL: its effect grows as |x| shrinks)
+    for scale in (1e-3, 0.37, 11.0, 250.0):
+        el0, dm0, am0 = HO.adj_mat_seer_input(x * scale, h, n_nodes)
+        el1, dm1, am1 = prepare_adj_mat_seer_input_hip((x * scale).to(DEV), h.to(DEV), n_nodes)
+        assert torch.equal(dm1.cpu(), dm0) and torch.equal(am1.cpu(), am0), scale
+    # the reference's own arithmetic: `distance_matrix` on the text-round-tripped coordinates (tools/make_golden.py)
+    g = load_golden("handoff_tensor_half.npz")
+    el1, dm1, am1 = prepare_adj_mat_seer_input_hip(g["x"].to(DEV), g["h"].to(DEV), g["n_nodes"])
+    assert torch.equal(el1.cpu(), g["elements"]) and torch.equal(dm1.cpu(), g["dist_mat"]) and torch.equal(am1.cpu(), g["adj_mat"])
+    el1, dm1, am1 = prepare_adj_mat_seer_input_hip(g["x"].to(DEV), g["h"].to(DEV), g["n_nodes"], connectivity=list(g["conn_cov"]))
+    assert torch.equal(dm1.cpu(), g["dist_mat"]) and torch.equal(am1.cpu(), g["adj_mat"])
 
 
 def test_handoff_ex_random_orders_and_connectivities_vs_oracle(gcn, gcn_sd):
     """f1: `mcg_handoff_ex` with an externally supplied atom order and connectivity (the two RDKit-owned decisions of
     `canonicalise`, mol_utils.py:110-126) against `host_oracle.adj_mat_seer_input(order=, conn=)`: random permutations
-    and random symmetric connectivities on ragged molecules (incl. n = 1, 42).  Elements and adjacency EXACT, distances to
-    fp32 rounding of the fp64 result (rtol 1e-6), permuted coordinates exact, GCN logits within 1e-4 of max|logits| of the
+    and random symmetric connectivities on ragged molecules (incl. n = 1, 42).  Elements, adjacency and (round 5: fp64
+    arithmetic in the kernel) distances BIT-EXACT, permuted coordinates exact, GCN logits within 1e-4 of max|logits| of the
     oracle GCN, bond argmax equal wherever the oracle's top-2 margin exceeds 100x the logit error."""
     from ml_conformer_generator_amd import _lib
     from ml_conformer_generator_amd.handoff import prepare_adj_mat_seer_input_hip
@@ -971,16 +1013,7 @@ def test_handoff_ex_random_orders_and_connectivities_vs_oracle(gcn, gcn_sd):
         el1, dm1, am1, xo = prepare_adj_mat_seer_input_hip(x.to(DEV), h.to(DEV), n_nodes, order=o, connectivity=c,
                                                            with_coords=True)
         assert torch.equal(el1.cpu(), el0)
-        assert torch.allclose(dm1.cpu(), dm0, rtol=1e-6, atol=1e-6)
-        if use_conn:
-            assert torch.equal(am1.cpu(), am0)
-        else:
-            rc = torch.zeros(36)
-            for z, r in HO._RCOV.items():
-                rc[z] = r
-            thr = 1.3 * (rc[el0].unsqueeze(1) + rc[el0].unsqueeze(2))
-            borderline = ((dm0 - thr).abs() < 1e-5) & (thr > 0)
-            assert torch.equal(am1.cpu()[~borderline], am0[~borderline])
+        assert torch.equal(dm1.cpu(), dm0) and torch.equal(am1.cpu(), am0)
         for b in range(B):
             n = int(n_nodes[b])
             perm = list(range(n)) if (o is None or o[b] is None) else o[b]
@@ -1403,6 +1436,20 @@ def test_integration_md_ctypes_stub_runs_as_documented(edm_sd, gcn_sd):
         ok, err, sc = close(out, ref)
         assert ok, (it, err, sc)
         del keep
+    # the stub checks a pair of mask tensors ONCE (the reference's loop passes the same two every step) and refuses
+    # anything but the canonical masks - also an accepted mask that was edited in place
+    nm_d, em_d = nm.to(DEV), em.to(DEV)
+    dyn(t.to(DEV), xh.to(DEV), nm_d, em_d, ctx.to(DEV))
+    checked = dyn._masks
+    dyn(t.to(DEV), xh.to(DEV), nm_d, em_d, ctx.to(DEV))
+    assert dyn._masks is checked
+    bad = em_d.clone()
+    bad[int(torch.nonzero(bad)[5, 0])] = 0.0
+    with pytest.raises(ValueError, match="canonical"):
+        dyn(t.to(DEV), xh.to(DEV), nm_d, bad, ctx.to(DEV))
+    em_d[int(torch.nonzero(em_d)[0, 0])] = 0.0
+    with pytest.raises(ValueError, match="canonical"):
+        dyn(t.to(DEV), xh.to(DEV), nm_d, em_d, ctx.to(DEV))
 
     class _RefSeer:
         device, dimension = DEV, 42
