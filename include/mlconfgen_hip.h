@@ -54,15 +54,18 @@ int mcg_egnn_set_precision(mcg_egnn* m, int mode);
 /* Model-level measurement options (defaults in brackets; none is needed for normal operation):
  *   MCG_OPT_X6_GEMM     [1]  f32x6 mode: 1 = node-side GEMMs on the split-operand kernel too, 0 = exact fp32 GEMMs
  *   MCG_OPT_GEMM_RN     [0]  wave tile width (column tiles) of the 32-row node GEMM kernel: 0 = cost model, 1..3
- *   MCG_OPT_GEMM_X6_RN  [0]  same for the split-operand GEMM kernel */
-enum { MCG_OPT_X6_GEMM = 1, MCG_OPT_GEMM_RN = 2, MCG_OPT_GEMM_X6_RN = 3 };
+ *   MCG_OPT_GEMM_X6_RN  [0]  same for the split-operand GEMM kernel
+ *   MCG_OPT_GEMM_BF16_LDS [0] bf16 mode: 0 = the LDS-staged 9-wave node GEMM from ~3 000 atoms on, 1 = never (32-row kernel),
+ *                            2 = whenever its shape limits allow (results are bit-identical either way) */
+enum { MCG_OPT_X6_GEMM = 1, MCG_OPT_GEMM_RN = 2, MCG_OPT_GEMM_X6_RN = 3, MCG_OPT_GEMM_BF16_LDS = 4 };
 /* Both setters may be called at any time between denoiser calls: a plan that has already captured its launches as a HIP
  * graph re-captures on its next call (the graph is keyed by the model's option epoch). */
 int mcg_egnn_set_option(mcg_egnn* m, int option, int value);
 
 /* Measurement / test hook: node and GCN GEMM launches ISSUED (plainly or into a graph capture) by this process since the
  * last reset, counts_host[family * 8 + rn] with family 0 = 32-row fp32 kernel, 1 = 32-row bf16 kernel, 2 = 16-row-tile fp32
- * kernel, 3 = split-operand kernel and rn = column tiles per wave - how a test sees that an option changed launch shapes. */
+ * kernel, 3 = split-operand kernel and rn = column tiles per wave (family 1, slot 7 = the LDS-staged 9-wave bf16 kernel) - how a
+ * test sees that an option changed launch shapes. */
 int mcg_debug_gemm_launches(int64_t* counts_host, int reset);
 
 /* ---- Batch plan.  Replaces the per-call `get_adj_matrix` edge-list rebuild (egnn.py:475,515-541)

@@ -263,7 +263,7 @@ int gemm(const float* A1, int lda1, int K1, const float* A2, int lda2, int K2, c
         return MCG_OK;
     }
     if (Bp16) { g.Bp = reinterpret_cast<const float*>(Bp16); g.a2_rows = a2_rows; g.a2_nsum = a2_nsum; }
-    MCG_HIP(mcg_gemm_launch(g, s, Bp16 != nullptr, opt ? opt->gemm_rn : 0));
+    MCG_HIP(mcg_gemm_launch(g, s, Bp16 != nullptr, opt ? opt->gemm_rn : 0, opt ? opt->gemm_bf16_lds : 0));
     return MCG_OK;
 }
 

@@ -90,6 +90,7 @@ struct mcg_egnn {
     // options (mcg_egnn_set_option)
     bool x6_gemm = true;        // f32x6 mode: node-side GEMMs on the split-operand kernel too
     int gemm_rn = 0, gemm_x6_rn = 0;   // wave tile width of the node GEMMs (0 = the launcher's cost model)
+    int gemm_bf16_lds = 0;             // MCG_OPT_GEMM_BF16_LDS: 0 auto, 1 never, 2 whenever the shape allows
     uint32_t opt_epoch = 0;     // bumped by mcg_egnn_set_precision / mcg_egnn_set_option: part of the captured graph's key,
                                 // so a plan that already captured its launches re-captures after a change
     float *emb_wT = nullptr, *emb_b = nullptr, *out_w = nullptr, *out_b = nullptr;

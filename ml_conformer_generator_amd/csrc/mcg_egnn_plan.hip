@@ -188,11 +188,14 @@ static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, c
     // 2 808: 16.92 / 17.12 / 16.05 (4: 16.72);  3 005 (config 3 shape, ragged): - / 17.37 / 17.11 (4: 18.0);
     // 4 212: 3 ranges 24.99, 4: 23.94, 5: 26.7.  Hence the table below.  Other plans (64-row units of the bf16 / split-operand
     // kernels) keep round 1's rule; the split-operand modes' host mirror asks for two ranges explicitly (f32x6 at
-    // config 2: 3.53 -> 3.18 ms per call - their edge kernel is short against the node phase).
+    // config 2: 3.53 -> 3.18 ms per call - their edge kernel is short against the node phase).  Round 5, 64-row bf16 plans with
+    // the LDS-staged node GEMM, ms per call with 1 / 2 / 3 ranges at the 256-ragged shape (12 020 tiles): 4.60 / 4.63 / 5.45
+    // (round 4, 32-row GEMM: 5.55 / 5.25 / 5.74) - the node phase no longer needs another range's edge kernel to hide under:
+    // one range up to 16 384 tiles.
     int parts = 1;
     if (n_ranges > 0) parts = n_ranges;
     else if (p->MT == 1) parts = p->n_mtiles < 3600 ? 1 : p->n_mtiles < 5200 ? 2 : p->n_mtiles < 14000 ? 3 : 4;
-    else parts = p->n_mtiles >= 8192 ? 2 : 1;
+    else parts = p->n_mtiles >= 16384 ? 2 : 1;
     if (parts < 2 || B < 2 * parts || p->n_rows < 4096) return MCG_OK;
     const std::vector<int> cuts = mcg_plan_range_cuts(B, n_nodes_host, parts);     // host-only, sanitizer-covered
     for (size_t k = 0; k + 1 < cuts.size(); ++k) {

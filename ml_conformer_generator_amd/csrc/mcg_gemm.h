@@ -267,6 +267,240 @@ __global__ __launch_bounds__(256) void mcg_gemm_bf16_kernel(McgGemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// bf16 node GEMM for LARGE batches (round 5): the activation block of a workgroup goes through LDS ONCE.
+// PMC of the kernel above at 6 895 rows (profiles/round5_c3_bf16_pmc_stall.csv): 67 % of its wave-cycles wait to ISSUE
+// (SQ_WAIT_INST_ANY) with the matrix pipe 5 % busy - every wave loads its own copy of the 32 activation rows (9 column
+// groups re-read each row block: 364 MB through the vector L1s per launch for 23 MB of activations) and the texture
+// addresser is the bottleneck.  Here a workgroup owns 32 rows x 27 column tiles (ALL columns of a 432-wide output; the
+// 864-wide first-layer GEMM takes two workgroups per row block): its 9 waves load the fp32 block cooperatively, sum the
+// gathered partial rows, divide by 100, round to bf16 and park the result in LDS as ready-made MFMA fragments
+// ([k-block][row tile][lane] x 16 B: a wave's ds_read_b128 is 1 KB contiguous, conflict-free) - ONE barrier, after which
+// each wave walks K alone: two fragment reads + its three weight fragments (a 4-deep register ring straight from L2;
+// weights are per-wave disjoint, there is nothing to share) + six MFMAs per 32-k block.  Same operand values, same k order
+// per output element as the kernel above: bit-identical results (tests/test_hip_parity.py).
+constexpr int MCG_LDSG_WAVES = 9, MCG_LDSG_RN = 3, MCG_LDSG_THREADS = MCG_LDSG_WAVES * 64, MCG_LDSG_TILES = MCG_LDSG_WAVES * MCG_LDSG_RN;
+constexpr int MCG_LDSG_MAX_BLOCKS = 28;                 // k-blocks of 32 a workgroup can park: 28 x 2 KB = 56 KB of LDS
+
+__device__ __forceinline__ void mcg_gemm_side_job_n(const McgGemmArgs& p, int block, int threads) {
+    const int idx = block * threads + (int)threadIdx.x;
+    const int v = idx >> 2, comp = idx & 3;
+    if (v < p.side_M && comp < 3) {
+        const int4 sl = p.side_slots[v];
+        p.side_x[(size_t)v * 4 + comp] += (((p.side_u[(size_t)sl.x * 4 + comp] + p.side_u[(size_t)sl.y * 4 + comp]) + p.side_u[(size_t)sl.z * 4 + comp]) +
+                                           p.side_u[(size_t)sl.w * 4 + comp]) / 100.0f;
+    }
+}
+
+template <int GATHER, bool RESID, bool SEG2, int RING>
+__global__ __launch_bounds__(MCG_LDSG_THREADS) void mcg_gemm_bf16_lds_kernel(McgGemmArgs p) {
+    __shared__ bf16x8 sA[MCG_LDSG_MAX_BLOCKS * 2 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int nblk = p.gemm_blocks > 0 ? p.gemm_blocks : (int)gridDim.x;        // (+ side-job workgroups behind them)
+    if ((int)blockIdx.x >= nblk) { mcg_gemm_side_job_n(p, (int)blockIdx.x - nblk, MCG_LDSG_THREADS); return; }
+    const int col_groups = (p.n_tiles + MCG_LDSG_TILES - 1) / MCG_LDSG_TILES;
+    const int wg = MCG_GEMM_BLOCK(blockIdx.x, nblk);
+    const int row0 = (wg / col_groups) * 32;
+    const int nt0 = (wg % col_groups) * MCG_LDSG_TILES + wid * MCG_LDSG_RN;
+    constexpr int RN = MCG_LDSG_RN;
+    bool nvalid[RN];
+    int ncl[RN];
+#pragma unroll
+    for (int n = 0; n < RN; ++n) {
+        nvalid[n] = nt0 + n < p.n_tiles;
+        ncl[n] = nvalid[n] ? nt0 + n : 0;
+    }
+    const int b1 = p.K1 > 0 ? mcg_kblocks16(p.K1) : 0, b2 = (SEG2 && p.K2 > 0) ? mcg_kblocks16(p.K2) : 0;
+    const int blocks = b1 + b2;
+
+    // ---- the weight ring starts first: its loads fly while the activation block is being parked
+    const bf16x8* bseg = reinterpret_cast<const bf16x8*>(p.Bp);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8*>(bseg), 0, 0xffffffff, 0x00020000);
+    auto ld = [](const __amdgpu_buffer_rsrc_t& r, unsigned v, int so) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)v, so, 0); };
+    unsigned obn[RN];
+#pragma unroll
+    for (int n = 0; n < RN; ++n) obn[n] = (unsigned)(ncl[n] * 64 + lane) * 16u;
+    const int bbytes = p.n_tiles * 64 * 16;                  // bytes per k-block of the pack (both segments: same n_tiles, contiguous)
+    bf16x8 Br[RING][RN];
+    auto load_w = [&](int slot, int kb) {
+        kb = kb < blocks ? kb : blocks - 1;
+#pragma unroll
+        for (int n = 0; n < RN; ++n) Br[slot][n] = __builtin_bit_cast(bf16x8, ld(rs_b, obn[n], kb * bbytes));
+    };
+#pragma unroll
+    for (int r = 0; r < RING; ++r) load_w(r, r);
+
+    int rr[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { const int r = row0 + 16 * m + c; rr[m] = r < p.M ? r : p.M - 1; }
+
+    // ---- park segment 1 of the activation block: fragment f = 2 * kb + m (row tile m of k-block kb); a wave takes the
+    //      fragment pairs wid, wid + 9, ... - both loads of a pair in flight together
+    {
+        const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A1), 0, 0xffffffff, 0x00020000);
+        for (int f0 = wid * 2; f0 < 2 * b1; f0 += 2 * MCG_LDSG_WAVES) {
+            f32x4 v[2][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int f = f0 + q, kb = f >> 1, m = f & 1;
+                const unsigned off = (unsigned)(rr[m] * p.lda1 + 32 * kb + 8 * g) * 4u;
+                v[q][0] = __builtin_bit_cast(f32x4, ld(rs_a1, off, 0));
+                v[q][1] = __builtin_bit_cast(f32x4, ld(rs_a1, off, 16));
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int f = f0 + q, kb = f >> 1;
+                const int k0 = 32 * kb + 8 * g;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {                       // k beyond the segment: zero (the packed weights are zero there too)
+                    if (k0 + e >= p.K1) v[q][0][e] = 0.f;
+                    if (k0 + 4 + e >= p.K1) v[q][1][e] = 0.f;
+                }
+                sA[f * 64 + lane] = mcg_pack_bf16(v[q][0], v[q][1]);
+            }
+        }
+    }
+    // ---- segment 2: plain rows, or the sum of an atom's <= GATHER partial rows / 100 (slot order, then mcg_div100, then the
+    //      bf16 rounding - exactly the A-loader of mcg_gemm_bf16_kernel).  Its loads are ISSUED here, in front of the first
+    //      barrier, and consumed behind the K loop over segment 1 (their latency hides under it); a wave owns the fragments
+    //      wid, wid + 9, wid + 18, wid + 27 (2 * b2 <= 28 of them)
+    constexpr int NS = GATHER >= 2 ? GATHER : 1;
+    constexpr int S2F = SEG2 ? 4 : 0;
+    f32x4 s2[SEG2 ? 4 : 1][NS][2];
+    const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A2 ? p.A2 : p.A1), 0, 0xffffffff, 0x00020000);
+    auto seg2_issue = [&](int j) {
+        int f = wid + j * MCG_LDSG_WAVES;
+        f = f < 2 * b2 ? f : 2 * b2 - 1;                                // (clamped: unconditional loads, the store is predicated)
+        const int kb = f >> 1, m = f & 1;
+        int rows[4] = {rr[m], rr[m], rr[m], rr[m]};
+        if constexpr (GATHER >= 2) { const int4 sl = p.a2_rows[rr[m]]; rows[0] = sl.x; rows[1] = sl.y; rows[2] = sl.z; rows[3] = sl.w; }
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const unsigned off = (unsigned)(rows[q] * p.lda2 + 32 * kb + 8 * g) * 4u;
+            s2[j][q][0] = __builtin_bit_cast(f32x4, ld(rs_a2, off, 0));
+            s2[j][q][1] = __builtin_bit_cast(f32x4, ld(rs_a2, off, 16));
+        }
+    };
+    auto seg2_park = [&](int j) {
+        const int f = wid + j * MCG_LDSG_WAVES;
+        if (f >= 2 * b2) return;
+        const int k0 = 32 * (f >> 1) + 8 * g;
+        f32x4 lo = s2[j][0][0], hi = s2[j][0][1];
+        if constexpr (GATHER >= 2) {
+#pragma unroll
+            for (int q = 1; q < NS; ++q) { lo += s2[j][q][0]; hi += s2[j][q][1]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lo[e] = mcg_div100(lo[e]); hi[e] = mcg_div100(hi[e]); }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (k0 + e >= p.K2) lo[e] = 0.f;
+            if (k0 + 4 + e >= p.K2) hi[e] = 0.f;
+        }
+        sA[(2 * b1 + f) * 64 + lane] = mcg_pack_bf16(lo, hi);
+    };
+    // the residual rows (W4: h) are requested here, a whole K loop ahead of their use
+    f32x4 eres[RESID ? 2 : 1][RN];
+    if constexpr (RESID) {
+#pragma unroll
+        for (int n = 0; n < RN; ++n) {
+            const int col = ncl[n] * 16 + 4 * g;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int orow = row0 + 16 * m + c;
+                eres[m][n] = (orow < p.M && col + 3 < p.n_store) ? *reinterpret_cast<const f32x4*>(p.resid + (size_t)orow * p.ldr + col)
+                                                                  : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+    constexpr bool OVERLAP2 = SEG2 && GATHER <= 2;  // (4-row gathers would hold 128 registers across the loop: park them up front)
+    if (SEG2 && b2 > 0) {
+        if constexpr (OVERLAP2) {
+#pragma unroll
+            for (int j = 0; j < S2F; ++j) seg2_issue(j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < S2F; ++j) { seg2_issue(j); seg2_park(j); }
+        }
+    }
+    __syncthreads();
+
+    // ---- K loop: barrier-free, one wave = 2 x RN accumulators (transposed: weights as the MFMA A operand, see above)
+    f32x4 acc[2][RN];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < RN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int slot, int kb) {
+        const bf16x8 A0 = sA[(2 * kb) * 64 + lane];
+        const bf16x8 A1 = sA[(2 * kb + 1) * 64 + lane];
+#pragma unroll
+        for (int n = 0; n < RN; ++n) {
+            acc[0][n] = mcg_mfma_bf16(Br[slot][n], A0, acc[0][n]);
+            acc[1][n] = mcg_mfma_bf16(Br[slot][n], A1, acc[1][n]);
+        }
+    };
+    // blocks [k0, k1) with the ring freshly loaded with k0, k0 + 1, k0 + 2 (every slot index is a compile-time constant:
+    // a runtime slot would turn the ring into a scratch array)
+    auto k_loop = [&](int k0, int k1) {
+        int kb = k0;
+#pragma unroll 1
+        for (; kb + RING <= k1; kb += RING) {
+#pragma unroll
+            for (int r = 0; r < RING; ++r) {
+                compute(r, kb + r); __builtin_amdgcn_sched_barrier(0); load_w(r, kb + r + RING); __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RING - 1; ++r)
+            if (kb + r < k1) compute(r, kb + r);
+    };
+    if (SEG2 && b2 > 0 && OVERLAP2) {
+        k_loop(0, b1);
+#pragma unroll
+        for (int r = 0; r < RING; ++r) load_w(r, b1 + r);          // the ring restarts at the segment boundary (its loads fly
+#pragma unroll                                                     //  while segment 2 is being parked)
+        for (int j = 0; j < S2F; ++j) seg2_park(j);
+        __syncthreads();
+        k_loop(b1, blocks);
+    } else {
+        k_loop(0, blocks);
+    }
+
+    // ---- epilogue (bias, activation, residual; 16-byte stores of the transposed accumulators)
+#pragma unroll
+    for (int n = 0; n < RN; ++n) {
+        if (!nvalid[n]) continue;
+        const int col = (nt0 + n) * 16 + 4 * g;
+        if (col >= p.n_store) continue;
+        const f32x4 ebias = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int orow = row0 + 16 * m + c;
+            if (orow >= p.M) continue;
+            f32x4 v = acc[m][n] + ebias;
+            if (p.act == MCG_ACT_SILU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = mcg_silu(v[r]);
+            } else if (p.act == MCG_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if constexpr (RESID) v += eres[m][n];
+            float* dst = p.C + (size_t)orow * p.ldc + col;
+            if (col + 3 < p.n_store) {
+                *reinterpret_cast<f32x4*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (col + r < p.n_store) dst[r] = v[r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // "f32x6" variant: fp32-accurate GEMM on the bf16 matrix pipe (see k_edge_bf16_w64 in mcg_edge_bf16.hip).  Every fp32
 // operand is the exact sum of three bf16 parts; the six partial products of weight >= 2^-16 are accumulated in fp32.
 // The weights come pre-split ("B-pack16x3": [k-block][part][n-tile][lane][8], host side below).  The activation
@@ -838,9 +1072,41 @@ static inline hipError_t mcg_gemm16_launch(McgGemmArgs a, int rn, hipStream_t s,
     return hipGetLastError();
 }
 
-static inline hipError_t mcg_gemm_launch(const McgGemmArgs& a, hipStream_t s, bool bf16 = false, int rn_override = 0) {
+// bf16 kernel choice (mcg_egnn_set_option(MCG_OPT_GEMM_BF16_LDS)): 0 automatic - the LDS-staged kernel from
+// MCG_LDSG_MIN_ROWBLOCKS row blocks on, 1 never, 2 whenever its shape limits allow
+// measured per denoiser call, 32-row kernel -> LDS-staged kernel (ms; 27-atom molecules, profiles/round5_probes.txt):
+// 64 molecules (54 row blocks) 1.80 -> 1.89, 96 (81) 2.79 -> 2.42, 128 (108) 2.83 -> 2.72, 160 3.60 -> 3.19, 192 4.09 -> 3.70,
+// 256 ragged (216) 5.16 -> 4.60
+constexpr int MCG_LDSG_MIN_ROWBLOCKS = 80;
+
+static inline bool mcg_gemm_bf16_lds_ok(const McgGemmArgs& a) {
+    const int blocks = (a.K1 > 0 ? mcg_kblocks16(a.K1) : 0) + (a.K2 > 0 ? mcg_kblocks16(a.K2) : 0);
+    return blocks >= 1 && blocks <= MCG_LDSG_MAX_BLOCKS && a.n_tiles % MCG_LDSG_RN == 0;
+}
+
+static inline hipError_t mcg_gemm_bf16_lds_launch(const McgGemmArgs& a, hipStream_t s) {
+    McgGemmArgs b = a;
+    const int rowblocks = (a.M + 31) / 32;
+    const int col_groups = (a.n_tiles + MCG_LDSG_TILES - 1) / MCG_LDSG_TILES;
+    b.gemm_blocks = rowblocks * col_groups;
+    dim3 grid((unsigned)b.gemm_blocks);
+    if (a.side_x) grid.x += (unsigned)((a.side_M * 4 + MCG_LDSG_THREADS - 1) / MCG_LDSG_THREADS);
+    const int gather = (a.a2_rows != nullptr && a.K2 > 0) ? (a.a2_nsum > 2 ? 4 : 2) : 0;
+    mcg_count_gemm_launch(1, 7);                 // family 1 (bf16), slot 7 = the LDS-staged 9-wave kernel
+    // (ring depth 3: 4 / 6 stages measured no gain / spills at the 256-ragged shape - the K loop is not what these launches wait for)
+#define MCG_LDSG(G_, S2_) do { if (a.resid) hipLaunchKernelGGL((mcg_gemm_bf16_lds_kernel<G_, true, S2_, 3>), grid, dim3(MCG_LDSG_THREADS), 0, s, b); \
+                               else hipLaunchKernelGGL((mcg_gemm_bf16_lds_kernel<G_, false, S2_, 3>), grid, dim3(MCG_LDSG_THREADS), 0, s, b); } while (0)
+    if (gather == 4) MCG_LDSG(4, true); else if (gather == 2) MCG_LDSG(2, true); else if (a.K2 > 0) MCG_LDSG(0, true); else MCG_LDSG(0, false);
+#undef MCG_LDSG
+    return hipGetLastError();
+}
+
+static inline hipError_t mcg_gemm_launch(const McgGemmArgs& a, hipStream_t s, bool bf16 = false, int rn_override = 0,
+                                         int bf16_lds = 0) {
     if (a.M <= 0) return hipSuccess;
     const int rowblocks = (a.M + 31) / 32;
+    if (bf16 && bf16_lds != 1 && mcg_gemm_bf16_lds_ok(a) && (bf16_lds == 2 || rowblocks >= MCG_LDSG_MIN_ROWBLOCKS))
+        return mcg_gemm_bf16_lds_launch(a, s);
     // Wave tile width RN in {1,2,3} from a measured cost model (tools/native/gemm_bench.hip, MI355X; us of loop
     // time per wave and per 420 of K): with at most one wave per SIMD a wave costs u1[RN]; with many waves per
     // SIMD the SIMD retires one wave per uinf[RN] (the 3-wide tile degrades most when waves share a SIMD).

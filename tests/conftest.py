@@ -38,7 +38,10 @@ def sd_for(g):
     from ml_conformer_generator_amd.weights import synth_edm_state_dict
     key = (int(g["weight_seed"]), str(g["weight_recipe"]) if "weight_recipe" in g else "v2")
     if key not in _SD_CACHE:
-        _SD_CACHE[key] = synth_edm_state_dict(key[0], recipe=key[1])
+        if key[1].startswith("gain"):          # the contractive legacy recipe: nn.Linear-family init x gain ("gain0.3")
+            _SD_CACHE[key] = synth_edm_state_dict(key[0], weight_gain=float(key[1][4:]))
+        else:
+            _SD_CACHE[key] = synth_edm_state_dict(key[0], recipe=key[1])
     return _SD_CACHE[key]
 
 

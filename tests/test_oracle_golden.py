@@ -104,6 +104,36 @@ def test_inpaint():
     assert torch.equal(h.to(torch.int64), g["h"].to(torch.int64))
 
 
+def test_sampler_at_the_judged_step_counts():
+    """Round 5: the reference's own `forward` at T = 100 (BASELINE configs[1]: 101 denoiser calls) and `inpaint` at T = 250
+    with resample_steps = 1 (configs[4]: 501 calls) under recorded noise tapes, every 10th / 50th latent kept
+    (`e2e_T100_b2n27.npz`, `inpaint_T250_rs1_b2.npz`; contractive weights - the fixtures record that a one-ulp change of the
+    context moves the reference's own final x by 3e-7 / 6e-7 of max|x| there, and by 2.5 % with the untrained "v2d"
+    recipe, which therefore cannot pin anything at this length).  The oracle sampler replays both."""
+    g = load_golden("e2e_T100_b2n27.npz")
+    assert float(g["one_ulp_context_rel_dev"]) < 1e-5 < 1e-3 < float(g["one_ulp_context_rel_dev_v2d"])
+    nm = g["node_mask"]
+    s = DO.SamplerOracle(sd_for(g), int(g["T"]), noise_fn=TapeNoise(g["noise"]))
+    s.trace = []
+    x, h = s.forward(nm, edge_mask_of(nm), g["context"], 0)
+    assert s.noise_fn.pos == g["noise"].numel() and len(s.trace) == 100
+    zt = torch.stack(s.trace)[g["z_trace_index"].long()]
+    assert traj_violation(zt, g["z_trace"], rel=2e-5) <= 1.0, traj_violation(zt, g["z_trace"], rel=2e-5)
+    assert violation(x, g["x"]) <= 1.0
+    assert torch.equal(h.to(torch.int64), g["h"].to(torch.int64))
+    g = load_golden("inpaint_T250_rs1_b2.npz")
+    assert float(g["one_ulp_context_rel_dev"]) < 1e-5
+    nm = g["node_mask"]
+    s = DO.SamplerOracle(sd_for(g), int(g["T"]), noise_fn=TapeNoise(g["noise"]))
+    s.trace = []
+    x, h = s.inpaint(nm, edge_mask_of(nm), g["context"], g["z_known"], g["fixed_mask"], 1, 3)
+    assert s.noise_fn.pos == g["noise"].numel() and len(s.trace) == int(g["n_sampler_steps"]) == 500
+    zt = torch.stack(s.trace)[g["z_trace_index"].long()]
+    assert traj_violation(zt, g["z_trace"], rel=2e-5) <= 1.0, traj_violation(zt, g["z_trace"], rel=2e-5)
+    assert violation(x, g["x"]) <= 1.0
+    assert torch.equal(h.to(torch.int64), g["h"].to(torch.int64))
+
+
 def test_merge_fragments():
     g = load_golden("merge_T10_L10.npz")
     nm = g["node_mask"]

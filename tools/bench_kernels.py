@@ -18,6 +18,7 @@ ap.add_argument("--four-tile-units", default="0", help="mcg_plan_opts.four_tile_
 ap.add_argument("--ranges", type=int, default=0, help="mcg_plan_opts.n_ranges (0 = the library's choice)")
 ap.add_argument("--latency-mode", type=int, default=-1, help="mcg_plan_set_latency_mode: -1 auto, 0 four-tile units only, 1 k_edge_ns")
 ap.add_argument("--gemm-rn", type=int, default=0, help="mcg_egnn_set_option(MCG_OPT_GEMM_RN): wave tile width of the 32-row GEMM kernels")
+ap.add_argument("--bf16-lds", type=int, default=0, help="mcg_egnn_set_option(MCG_OPT_GEMM_BF16_LDS): 0 auto, 1 the 32-row kernel, 2 the LDS-staged kernel")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 dyn = EGNNDynamics(device=dev)
@@ -25,6 +26,8 @@ dyn.load_reference_state_dict(W.synth_edm_state_dict(1234))
 dyn.set_precision(a.dtype)
 if a.gemm_rn:
     dyn.set_option(_lib.OPT_GEMM_RN, a.gemm_rn)
+if a.bf16_lds:
+    dyn.set_option(_lib.OPT_GEMM_BF16_LDS, a.bf16_lds)
 if a.mols > 0:
     sizes = torch.full((a.mols,), a.atoms, dtype=torch.int32); N = a.atoms
 elif a.shape == "c2":

@@ -443,6 +443,74 @@ def main():
          x_perm=coords_perm, logits=logits, argmax=torch.argmax(logits, -1), margin=margin,
          order_dependent_entries=moved, gcn_weight_seed=4321)
 
+    # 10. the JUDGED step counts (round 5): BASELINE configs[1] runs T = 100 (101 denoiser calls), configs[4] T = 250 with
+    #     fixed-fragment inpainting and resample_steps = 1 (501 calls) - every fixture above is T <= 20.  The reference's own
+    #     `EquivariantDiffusion.forward` / `.inpaint` at those lengths under a recorded noise tape, with every 10th / 50th
+    #     latent of the trajectory.  Weights: the CONTRACTIVE recipe (nn.Linear-family init x 0.3, what bench.py's fragment
+    #     modes time).  The untrained "v2d" network amplifies a one-ulp change of the context to 2.5 % of max|x| over 100
+    #     steps IN THE REFERENCE ITSELF - no implementation can be pinned to such a trajectory - while the contractive one
+    #     moves by ~3e-7 of max|x|; both factors are measured here and stored.  What these fixtures pin is the ancestral loop
+    #     at its real length (schedule lookups at every level, the draw order and count of 101 / 751 noise tensors, the
+    #     blend / resample arithmetic of 250 levels); the network's internals are pinned by the "v2" fixtures above.
+    def amplification(run, x_ref):
+        x_pert = run(True)
+        return float((x_ref - x_pert).abs().max() / x_ref.abs().max())
+
+    sd_c = W.synth_edm_state_dict(1234, weight_gain=0.3)
+
+    def run_T100(sd_run, perturb, keep=None):
+        gm_ = build_edm(egnn, ed, 100, sd_run)
+        torch.manual_seed(51)
+        nm_, em_, ctx_ = mu.prepare_edm_input(2, dummy_ctx, norms, 27, 27, torch.device("cpu"))
+        if perturb:
+            ctx_ = torch.nextafter(ctx_, ctx_ + 1) * nm_                 # one ulp up, every context entry
+        tr = record_steps(gm_) if keep is not None else None
+        with NoiseTape() as tp, torch.no_grad():
+            x_, h_ = gm_(nm_, em_, ctx_, 0)
+        if keep is not None:
+            keep.update(nm=nm_, ctx=ctx_, tape=tp.flat(), trace=torch.stack(tr), h=h_)
+        return x_
+
+    k100 = {}
+    x = run_T100(sd_c, False, k100)
+    amp_c = amplification(lambda p: run_T100(sd_c, p), x)
+    x_v2d = run_T100(sd_d, False)
+    amp_d = amplification(lambda p: run_T100(sd_d, p), x_v2d)
+    idx = list(range(9, 100, 10))                                        # every 10th z_s (0-based call index)
+    print(f"e2e_T100: one-ulp context perturbation moves the final x by {amp_c:.3e} of max|x| (contractive), {amp_d:.3e} (v2d)")
+    save("e2e_T100_b2n27.npz", node_mask=k100["nm"], context=k100["ctx"], noise=k100["tape"], z_trace=k100["trace"][idx],
+         z_trace_index=np.array(idx), x=x, h=k100["h"], T=100, resample_steps=0, weight_seed=1234,
+         weight_recipe=np.array("gain0.3"), one_ulp_context_rel_dev=amp_c, one_ulp_context_rel_dev_v2d=amp_d)
+
+    def run_T250(perturb, keep=None):
+        gm_ = build_edm(egnn, ed, 250, sd_c)
+        torch.manual_seed(52)
+        nm_, em_, ctx_ = mu.prepare_edm_input(2, dummy_ctx, norms, 15, 19, torch.device("cpu"))
+        if perturb:
+            ctx_ = torch.nextafter(ctx_, ctx_ + 1) * nm_
+        zk = torch.zeros(2, 19, 11)
+        zk[:, :n_f, :3] = fxyz
+        zk[:, :n_f, 3:] = foh.float()
+        fm = torch.zeros(2, 19, 1)
+        fm[:, :n_f] = 1.0
+        tr = record_steps(gm_) if keep is not None else None
+        with NoiseTape() as tp, torch.no_grad():
+            x_, h_ = gm_.inpaint(nm_, em_, ctx_, zk, fm, 1, 3)
+        if keep is not None:
+            keep.update(nm=nm_, ctx=ctx_, tape=tp.flat(), trace=torch.stack(tr), h=h_, zk=zk, fm=fm)
+        return x_
+
+    k250 = {}
+    x = run_T250(False, k250)
+    amp_i = amplification(run_T250, x)
+    n_tr = int(k250["trace"].shape[0])
+    idx = list(range(49, n_tr, 50))
+    print(f"inpaint_T250: {n_tr} recorded sampler steps, one-ulp context perturbation moves the final x by {amp_i:.3e} of max|x|")
+    save("inpaint_T250_rs1_b2.npz", node_mask=k250["nm"], context=k250["ctx"], z_known=k250["zk"], fixed_mask=k250["fm"],
+         noise=k250["tape"], z_trace=k250["trace"][idx], z_trace_index=np.array(idx), n_sampler_steps=n_tr, x=x, h=k250["h"],
+         T=250, resample_steps=1, blend_power=3, weight_seed=1234, weight_recipe=np.array("gain0.3"),
+         one_ulp_context_rel_dev=amp_i)
+
 
 if __name__ == "__main__":
     main()
