@@ -243,15 +243,15 @@ __global__ __launch_bounds__(256, 2) void k_edge_lds_bf16(EdgeArgs p) {
 constexpr int W64_A_FLOATS = 2 * 4 * 64 * 4;          // A tile ring: [2][4 row tiles][64 lanes] x 16 B (per operand part)
 constexpr int W64_KP = 32 * ((H + 31) / 32);            // 448: k range of the padded 32-k blocks
 template <int SPLIT> constexpr int w64_lds_floats() { return 2 * HP + 2 * W64_KP + SPLIT * W64_A_FLOATS + 4 * 64 + 64 * 4; }   // 17 / 33 KiB
-
 // SPLIT = 1: bf16 operands (one product).  SPLIT = 3: "f32x6" - every fp32 operand is carried as the exact sum of
 // three bf16 parts (a = a1 + a2 + a3, |a2| <= 2^-8 |a|, |a3| <= 2^-16 |a|; same for the weights, split on the
 // host) and the six partial products of weight >= 2^-16 (a1 b1, a2 b1, a3 b1, a1 b2, a2 b2, a1 b3) are accumulated
 // in fp32: the dropped terms are <= 2^-23 relative, i.e. the contraction is fp32-accurate, on a matrix pipe that is
 // 16x faster per k than v_mfma_f32_16x16x4_f32 (6/16 of the exact kernel's matrix time).  The weight parts are
 // streamed part-major per 32-k block (stage = kb*3 + part); part p meets the activation parts 0 .. 2-p.
-template <bool EQUIV, int SPLIT>
+template <bool EQUIV, int SPLIT, bool BLK = false>
 __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
+    static_assert(!BLK || SPLIT == 1, "the blocked layer-1 input layout is the bf16 mode's");
     __shared__ __attribute__((aligned(16))) float lds[w64_lds_floats<SPLIT>()];
     float* const par = lds;                                              // b2 | wv
     float* const wdl = par + 2 * HP;                                     // wd | wd0 (layer-1 distance weights): read at
@@ -296,8 +296,19 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
     }
     // Operand addresses are (buffer descriptor in SGPRs) + (one 32-bit lane offset) + (scalar block offset): as
     // 64-bit per-lane pointers hipcc keeps ~20 VGPRs of addresses alive and the f32x6 variant spills.
-    const unsigned oa = (unsigned)(vi * (2 * HP) + 8 * g) * 4u;
-    const unsigned ob = (unsigned)(vj * (2 * HP) + HP + 8 * g) * 4u;
+    // BLK (bf16 mode, round 5): the layer-1 inputs come in the BLOCKED layout Pab[part][k-block][atom][32] the bf16 first-layer
+    // GEMM writes for these plans (mcg_gemm.h: c_blocked) instead of row-major [atom][864].  A tile's 16 rows are (i, j .. j+15):
+    // row-major, the gathered half is a 64-byte piece of each of 16 lines 3 456 B apart, twice per block - and scattered
+    // loads are what this kernel waits for (ablations at the 256-ragged shape, profiles/round5_probes.txt: no layer-1 input loads
+    // 108 us, both halves broadcast-like 133, as built 143, both halves scattered 161; the 1.2 GB weight stream costs 16).  Blocked,
+    // consecutive atoms of one k-block are consecutive 128-byte lines: the same 16 rows are two contiguous KiB.  Measured:
+    // 4.50 -> 4.44 ms per denoiser call (same-run A/B) - the lines touched per instruction are the same 16, only closer together;
+    // staging the gathered half through LDS (LDS-DMA, whole lines once per workgroup) and relabelling k so that a lane group
+    // reads 64 contiguous bytes were built too and measured no gain / slower (profiles/round5_probes.txt).
+    const unsigned oa = BLK ? (unsigned)(vi * 32 + 8 * g) * 4u : (unsigned)(vi * (2 * HP) + 8 * g) * 4u;
+    const unsigned ob = BLK ? (unsigned)(vj * 32 + 8 * g) * 4u : (unsigned)(vj * (2 * HP) + HP + 8 * g) * 4u;
+    const int blk_stride = BLK ? p.M * 128 : 128;               // bytes from one k-block of a part to the next
+    const int blk_part_b = BLK ? KB16 * p.M * 128 : 0;          // byte offset of the Pb part
     const __amdgpu_buffer_rsrc_t rs_pab = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pab), 0, 0xffffffff, 0x00020000);
     const float* wdp = wdl + 8 * g;
     const float* w0p = wdl + W64_KP + 8 * g;
@@ -331,8 +342,9 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
     };
     auto load_a = [&](int kb, f32x4 (&v)[4]) {
         kb = kb < KB16 ? kb : KB16 - 1;
-        v[0] = __builtin_bit_cast(f32x4, ld16(rs_pab, oa, 128 * kb));  v[1] = __builtin_bit_cast(f32x4, ld16(rs_pab, oa, 128 * kb + 16));
-        v[2] = __builtin_bit_cast(f32x4, ld16(rs_pab, ob, 128 * kb));  v[3] = __builtin_bit_cast(f32x4, ld16(rs_pab, ob, 128 * kb + 16));
+        const int so = blk_stride * kb;
+        v[0] = __builtin_bit_cast(f32x4, ld16(rs_pab, oa, so));  v[1] = __builtin_bit_cast(f32x4, ld16(rs_pab, oa, so + 16));
+        v[2] = __builtin_bit_cast(f32x4, ld16(rs_pab, ob, so + blk_part_b));  v[3] = __builtin_bit_cast(f32x4, ld16(rs_pab, ob, so + blk_part_b + 16));
     };
     // layer-1 finish + SiLU of my row tile for one k-block, written to ring half `half` as SPLIT bf16 parts
     auto agen_store = [&](const f32x4 (&v)[4], int kb, int half) {
@@ -389,14 +401,20 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
         for (int mt = 0; mt < 4; ++mt) af[mt] = a_lds[(half * 4 + mt) * 64 + lane];
         const int st = next_stage < NSTAGE ? next_stage : NSTAGE - 1;
         const int base = st * STAGE_BYTES;
+#ifndef MCG_W64_AGEN_POS
+#define MCG_W64_AGEN_POS 3
+#endif
+        if (MCG_W64_AGEN_POS < 0) { __builtin_amdgcn_sched_barrier(0); mid(); }      // (measurement switch: generation in front of the block's first MFMA)
 #pragma unroll
         for (int i = 0; i < NS_T; ++i) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) acc[mt][i] = mcg_mfma_bf16(af[mt], Bc[i], acc[mt][i]);
             __builtin_amdgcn_sched_barrier(0);
+#ifndef MCG_ABL_NOB          // (ablation switch: no weight refills - wrong results, an upper bound for any better weight delivery)
             Bc[i] = __builtin_bit_cast(bf16x8, i < NS_T - 1 ? ld16(rs_b, ov, base + i * 4 * 64 * 16) : ld16(rs_b, ov6, base));
+#endif
             __builtin_amdgcn_sched_barrier(0);
-            if (i == 3) mid();          // (position 0 / 1 / 3 / 5 measured: no difference)
+            if (i == MCG_W64_AGEN_POS) mid();          // (position 0 / 1 / 3 / 5 measured: no difference)
         }
     };
     // one k-block: [barrier] A-operand loads of block kb+1 | per weight part: MFMAs, then the B loads two stages
@@ -416,9 +434,13 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
         constexpr int SET = decltype(set_tag)::value;       // SPLIT = 1: the set that receives block kb + 2; the other holds kb + 1
         const int half = kb & 1;
         // (bf16: the request for block kb + 2 goes out BEFORE the rendezvous - it depends on nothing the barrier orders)
+#ifndef MCG_ABL_NOA          // (ablation switch: layer-1 inputs never reloaded)
         if (SPLIT == 1) { load_a(kb + 2, vset[SET]); __builtin_amdgcn_sched_barrier(0); }
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // my A-tile writes of the previous block
+#ifndef MCG_ABL_NOBAR        // (ablation switch: no rendezvous)
         asm volatile("s_barrier" ::: "memory");                      // A(kb) visible; A ring half^1 free
+#endif
         f32x4 v[4];
 #pragma unroll
         for (int part = 0; part < SPLIT; ++part) {
@@ -443,13 +465,26 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    // Issue ORDER of the prologue's loads matters beyond the prologue: vector-memory loads complete in order and a wait is
+    // "all but the N newest"; hipcc gives the loop's mid-block wait for the NEXT block's layer-1 inputs ONE N for every
+    // iteration - the smallest over all paths into the loop.  With the inputs of block 1 requested LAST here, the first
+    // iteration allowed only the 8 loads issued behind them, and every later iteration inherited that: the wait drained the
+    // weight refills issued ~0.7 blocks earlier although the inputs themselves were requested 1.5 blocks ahead.  Requested
+    // FIRST, with the 14 weight loads behind them, every path allows the 15 newer loads of the steady state.
+    f32x4 v_first[4];
+    if constexpr (SPLIT == 1) {
+        load_a(0, v_first);
+        load_a(1, vset[SPLIT == 1 ? 1 : 0]);      // block 1 -> set 1 (consumed in the middle of block 0)
+        __builtin_amdgcn_sched_barrier(0);        // (pinned: left alone the scheduler sinks these behind the weight loads again)
+    }
     load_b(Bq[0], 0);
     load_b(Bq[1], 1);
     __syncthreads();                              // wd | wd0 staged
-    {
+    if constexpr (SPLIT == 1) {
+        agen_store(v_first, 0, 0);
+    } else {
         f32x4 v[4];
         load_a(0, v);
-        if (SPLIT == 1) load_a(1, vset[SPLIT == 1 ? 1 : 0]);      // block 1 -> set 1 (consumed in the middle of block 0)
         agen_store(v, 0, 0);
     }
 #pragma unroll 1
@@ -471,13 +506,14 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
         if (nt >= NT) continue;
         const float b2 = par[nt * 16 + c], wv = par[HP + nt * 16 + c];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float m = mcg_silu(acc[mt][i][r] + b2);
                 acc[mt][i][r] = m;
                 part[mt][r] = fmaf(wv, m, part[mt][r]);
             }
+        }
     }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -529,34 +565,27 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
 #pragma unroll
         for (int i = 0; i < NS_T; ++i) d[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if constexpr (SPLIT == 1) {
-            // bf16 mode: the segmented, gate-scaled sum on the bf16 pipe with two-part operands (hi + lo, three
-            // products: relative error 2^-16 on a quantity the mode's 3e-3 tolerance does not see) instead of 16
-            // fp32 MFMAs per column tile - 6 x 16 cycles instead of 16 x 32.  Contraction slot j of lane group g
-            // stands for row (tile 2h + j/4, 4g + j%4) on BOTH operands, so the B operand is just the lane's own
-            // accumulator registers of the two row tiles and the A operand its own gate values.
-            auto split2 = [](const float (&v)[8], bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) hi[j] = (__bf16)v[j];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) lo[j] = (__bf16)(v[j] - (float)hi[j]);
-            };
+            // bf16 mode: the segmented, gate-scaled sum is ONE MORE bf16 contraction (D[seg][col] = sum_row S[seg][row] m[row][col],
+            // S = gate or 0): its operands - the gate and the message - are rounded to bf16 like the operands of every other
+            // MFMA of the mode, fp32 accumulate; 2 x 16-cycle MFMAs per column tile instead of 16 x 32 on the fp32 pipe.
+            // Contraction slot j of lane group g stands for row (tile 2h + j/4, 4g + j%4) on BOTH operands, so the B operand is
+            // just the lane's own accumulator registers of the two row tiles and the A operand its own gate values.
+            // (Rounds 1-4 carried both operands as hi + lo pairs and issued three products per tile pair (relative error
+            //  2^-16): 280 more VALU instructions and 28 more MFMAs per wave in the kernel's instruction-heaviest part for
+            //  precision the next consumer - the node GEMM, which rounds the aggregate to bf16 - throws away; measured at the
+            //  256-ragged shape: 146.3 -> 140.5 us per launch, deviation from the bf16 emulation / the fp32 path unchanged
+            //  (7.4e-4 / 1.2e-3 -> 8.1e-4 / 1.1e-3 of max|out|; profiles/round5_probes.txt).)
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
-                float gv[8];
+                bf16x8 g_hi;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) gv[j] = sel[2 * h2 + (j >> 2)][j & 3];
-                bf16x8 g_hi, g_lo;
-                split2(gv, g_hi, g_lo);
+                for (int j = 0; j < 8; ++j) g_hi[j] = (__bf16)sel[2 * h2 + (j >> 2)][j & 3];
 #pragma unroll
                 for (int i = 0; i < NS_T; ++i) {
-                    float mv[8];
+                    bf16x8 m_hi;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) mv[j] = acc[2 * h2 + (j >> 2)][i][j & 3];
-                    bf16x8 m_hi, m_lo;
-                    split2(mv, m_hi, m_lo);
+                    for (int j = 0; j < 8; ++j) m_hi[j] = (__bf16)acc[2 * h2 + (j >> 2)][i][j & 3];
                     d[i] = mcg_mfma_bf16(g_hi, m_hi, d[i]);
-                    d[i] = mcg_mfma_bf16(g_lo, m_hi, d[i]);
-                    d[i] = mcg_mfma_bf16(g_hi, m_lo, d[i]);
                 }
             }
         } else {
@@ -590,5 +619,7 @@ hipError_t mcg_launch_edge_bf16_16(const EdgeArgs& a, bool equiv, hipStream_t s,
 // a.n_waves = 64-row units of an edge_mt = 4 plan; a.Bp = bf16 pack (x6 = false) or three-part pack (x6 = true)
 hipError_t mcg_launch_edge_w64(const EdgeArgs& a, bool equiv, bool x6, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
     if (x6) return equiv ? edge_launch(k_edge_bf16_w64<true, 3>, a.n_waves, s, a, t0, t1) : edge_launch(k_edge_bf16_w64<false, 3>, a.n_waves, s, a, t0, t1);
+    if (a.pab_blocked)
+        return equiv ? edge_launch(k_edge_bf16_w64<true, 1, true>, a.n_waves, s, a, t0, t1) : edge_launch(k_edge_bf16_w64<false, 1, true>, a.n_waves, s, a, t0, t1);
     return equiv ? edge_launch(k_edge_bf16_w64<true, 1>, a.n_waves, s, a, t0, t1) : edge_launch(k_edge_bf16_w64<false, 1>, a.n_waves, s, a, t0, t1);
 }

@@ -177,6 +177,9 @@ static bool edge_wgc(const mcg_egnn* m, const mcg_plan* pl) {
     return pl->wgc && pl->MT == 1 && !m->bf16 && !m->x6 && !edge_latency_kernel(pl);
 }
 
+#ifndef MCG_PAB_BLOCKED
+#define MCG_PAB_BLOCKED 1          // (measurement switch: 0 = row-major layer-1 inputs in the bf16 mode too)
+#endif
 int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipStream_t s, bool bf16 = false, bool x6 = false,
              bool wgc = false) {
     if (pl->n_waves == 0) return MCG_OK;
@@ -187,6 +190,8 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
     const mcg_plan::UnitTables& T = pl->units();
     a.wg_info = T.wg_info; a.U = equiv ? pl->Ux : pl->U;
     a.n_full_wg = T.n_full_wg; a.Bp4 = L.w2_Bp4;
+    a.M = pl->M;
+    a.pab_blocked = (bf16 && pl->MT == 4 && MCG_PAB_BLOCKED) ? 1 : 0;      // the bf16 first-layer GEMM wrote pab blocked for these plans (run_gcl / run_equiv)
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (pl->edge_timing && *pl->edge_timing_next < pl->edge_timing->size()) {     // mcg_bench_edge_incall
         mcg_plan::EdgeTiming& e = (*pl->edge_timing)[(*pl->edge_timing_next)++];
@@ -235,7 +240,7 @@ static long mcg_simd_count() {
 int gemm(const float* A1, int lda1, int K1, const float* A2, int lda2, int K2, const float* Bp, const float* bias,
          const float* resid, int ldr, float* C, int ldc, int M, int n_tiles, int n_store, int act, hipStream_t s,
          const uint16_t* Bp16 = nullptr, const uint16_t* Bp16x3 = nullptr, mcg_plan* side = nullptr, int rows16 = 0,
-         const int4* a2_rows = nullptr, int a2_nsum = 2, const mcg_egnn* opt = nullptr) {
+         const int4* a2_rows = nullptr, int a2_nsum = 2, const mcg_egnn* opt = nullptr, bool c_blocked = false) {
     McgGemmArgs g{};
     g.A1 = A1; g.lda1 = lda1; g.K1 = K1; g.A2 = A2; g.lda2 = lda2; g.K2 = K2; g.Bp = Bp; g.bias = bias;
     g.resid = resid; g.ldr = ldr; g.C = C; g.ldc = ldc; g.M = M; g.n_tiles = n_tiles; g.n_store = n_store; g.act = act;
@@ -262,7 +267,7 @@ int gemm(const float* A1, int lda1, int K1, const float* A2, int lda2, int K2, c
         MCG_HIP(mcg_gemm_x6_launch(g, s, opt ? opt->gemm_x6_rn : 0));
         return MCG_OK;
     }
-    if (Bp16) { g.Bp = reinterpret_cast<const float*>(Bp16); g.a2_rows = a2_rows; g.a2_nsum = a2_nsum; }
+    if (Bp16) { g.Bp = reinterpret_cast<const float*>(Bp16); g.a2_rows = a2_rows; g.a2_nsum = a2_nsum; g.c_blocked = c_blocked ? 1 : 0; }
     MCG_HIP(mcg_gemm_launch(g, s, Bp16 != nullptr, opt ? opt->gemm_rn : 0, opt ? opt->gemm_bf16_lds : 0));
     return MCG_OK;
 }
@@ -295,7 +300,8 @@ int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s, bool keep
     //  no side job: apply it first)
     if (x6g) { if (int e = apply_pending_x(pl, s)) return e; }
     if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
-                     MCG_ACT_NONE, s, lp ? E.pab_Bp16 : nullptr, x6g ? E.pab_Bp16x3 : nullptr, pl, pab_rows16(M), nullptr, 2, m)) return e;
+                     MCG_ACT_NONE, s, lp ? E.pab_Bp16 : nullptr, x6g ? E.pab_Bp16x3 : nullptr, pl, pab_rows16(M), nullptr, 2, m,
+                     lp && pl->MT == 4 && MCG_PAB_BLOCKED)) return e;          // (bf16, 64-row units: pab in the blocked layout the edge kernel reads)
     if (int e = apply_pending_x(pl, s)) return e;              // (only if the GEMM above could not carry it)
     if (int e = run_edge(pl, E, false, pl->P, s, lp, m->x6, wgc)) return e;
     const int4* gather = nullptr;
@@ -330,7 +336,7 @@ int run_equiv(const mcg_egnn* m, mcg_plan* pl, int block, hipStream_t s) {
     const bool wgc = edge_wgc(m, pl);
     if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
                      MCG_ACT_NONE, s, m->bf16 ? E.pab_Bp16 : nullptr, (m->x6 && m->x6_gemm) ? E.pab_Bp16x3 : nullptr, nullptr,
-                     pab_rows16(M), nullptr, 2, m)) return e;
+                     pab_rows16(M), nullptr, 2, m, m->bf16 && pl->MT == 4 && MCG_PAB_BLOCKED)) return e;
     if (int e = run_edge(pl, E, true, pl->Px, s, m->bf16, m->x6, wgc)) return e;
     if (wgc) {
         pl->x_pending = true;          // applied by the next launch that can carry it (next block's first GEMM / k_output)

@@ -29,6 +29,7 @@
 
 constexpr int MCG_H = 420;        // hidden_nf (conformer_generator.py:70)
 constexpr int MCG_HP = 432;       // padded to 27 column tiles of 16
+constexpr int MCG_PAB_BLOCKED_FLOATS = 2 * 14 * 32;      // per atom, blocked layer-1 input layout of the bf16 mode (896 >= 2 * HP)
 constexpr int MCG_NT = 27;
 constexpr int MCG_KSTEPS = MCG_H / 4;   // 105 MFMA k-steps
 constexpr int MCG_IN_NF = 12;     // 8 classes + time + 3 context
@@ -58,6 +59,8 @@ struct EdgeArgs {
     float* U;
     int n_full_wg;          // workgroups [0, n_full_wg) take four tiles each (LDS-staged body), the rest ONE tile (quarter-tile body)
     const float* Bp4;       // the same second-layer weights as B-pack4 (mcg_gemm.h): 16 B per lane and 16-k group
+    int pab_blocked;        // 64-row bf16 kernel: pab is [2 parts][14 k-blocks][M][32] (mcg_gemm.h c_blocked) instead of [M][864]
+    int M;                  // atoms (rows of pab)
 };
 
 // launchers of the edge kernel families (each returns a hipError_t from hipGetLastError).  `t0` / `t1` (optional): events

@@ -95,7 +95,7 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, const m
     const size_t M1 = (size_t)(p->M > 0 ? p->M : 1);
     struct { float** ptr; size_t n; } bufs[] = {
         // (+64 floats: the bf16 kernels read activation rows up to k = 447, i.e. 16 floats past the last row)
-        {&p->x, M1 * 4}, {&p->x0, M1 * 4}, {&p->h, M1 * HP + 64}, {&p->h2, M1 * HP + 64}, {&p->pab, M1 * 2 * HP + 64},
+        {&p->x, M1 * 4}, {&p->x0, M1 * 4}, {&p->h, M1 * HP + 64}, {&p->h2, M1 * HP + 64}, {&p->pab, M1 * MCG_PAB_BLOCKED_FLOATS + 64},
         {&p->agg, M1 * HP + 64}, {&p->t1, M1 * HP + 64}, {&p->P, (size_t)(p->n_pslots + 1) * HP + 64}, {&p->Px, (size_t)(p->n_pslots + 1) * 4},
         {&p->U, (size_t)(max_uslots + 1) * HP + 64}, {&p->Ux, (size_t)(max_uslots + 1) * 4}};
     size_t ws_bytes = 0;

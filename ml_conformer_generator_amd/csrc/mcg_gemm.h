@@ -45,7 +45,19 @@ struct McgGemmArgs {
     // x[v][0..2] += (side_u[s.x] + side_u[s.y] + side_u[s.z] + side_u[s.w]) / 100 - the coordinate update of the previous block (egnn.py:128-148)
     const float* side_u; const int4* side_slots; float* side_x; int side_M;
     int gemm_blocks;                        // workgroups of the GEMM proper (set by the launcher)
+    // bf16 kernels only: C is the BLOCKED layer-1 input layout of the bf16 edge kernel, C[part][k-block][row][32] with
+    // column = part * 432 + 32 * k-block + (0..31): the 16 rows (i, j .. j+15) of an edge tile then read their gathered half as
+    // contiguous KiB instead of one 64-byte piece from each of 16 rows 3 456 B apart (mcg_edge_bf16.hip, BLK)
+    int c_blocked;
 };
+
+// address of C[row][16 * nt + 4 * g .. + 3] (nt = column tile): row-major, or the blocked layout above (27 column tiles per part,
+// 14 k-blocks of two tiles each; the odd half of the 14th block stays zero)
+__device__ __forceinline__ float* mcg_gemm_c_ptr(const McgGemmArgs& p, int orow, int nt, int g) {
+    if (!p.c_blocked) return p.C + (size_t)orow * p.ldc + nt * 16 + 4 * g;
+    const int part = nt >= 27 ? 1 : 0, ntp = nt - 27 * part;
+    return p.C + ((size_t)(part * 14 + (ntp >> 1)) * p.M + orow) * 32 + (ntp & 1) * 16 + 4 * g;
+}
 
 // Side job of the fp32 node GEMM launches (workgroups beyond the GEMM's own grid): the coordinate update of the
 // previous EquivariantBlock, x[v] += (u[s.x] + u[s.y] + u[s.z] + u[s.w]) / 100 (egnn.py:128-148) - independent data, saves a launch.
@@ -254,7 +266,7 @@ __global__ __launch_bounds__(256) void mcg_gemm_bf16_kernel(McgGemmArgs p) {
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
             v += eres[m][n];
-            float* dst = p.C + (size_t)orow * p.ldc + col;
+            float* dst = mcg_gemm_c_ptr(p, orow, nt0 + n, g);
             if (col + 3 < p.n_store) {
                 *reinterpret_cast<f32x4*>(dst) = v;       // (4-byte aligned is enough for a global dwordx4 store)
             } else {                                       // ragged right edge (GCN: 210 columns)
@@ -488,7 +500,7 @@ __global__ __launch_bounds__(MCG_LDSG_THREADS) void mcg_gemm_bf16_lds_kernel(Mcg
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
             if constexpr (RESID) v += eres[m][n];
-            float* dst = p.C + (size_t)orow * p.ldc + col;
+            float* dst = mcg_gemm_c_ptr(p, orow, nt0 + n, g);
             if (col + 3 < p.n_store) {
                 *reinterpret_cast<f32x4*>(dst) = v;
             } else {
@@ -864,7 +876,7 @@ __global__ __launch_bounds__(256) void mcg_gemm_kernel(McgGemmArgs p) {
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
             v += eres[m][n];
-            float* dst = p.C + (size_t)orow * p.ldc + col;
+            float* dst = mcg_gemm_c_ptr(p, orow, nt0 + n, g);
             if (col + 3 < p.n_store) {
                 *reinterpret_cast<f32x4*>(dst) = v;       // (4-byte aligned is enough for a global dwordx4 store)
             } else {                                       // ragged right edge (GCN: 210 columns)
