@@ -391,14 +391,19 @@ def config4_share(args, gsd, ctx, dev, fence):
     g4.set_diffusion_steps(250)
     el, ms, fin, vf = timed_passes(g4, ctx, 256, 27, 12, frag, 1, 0, fence, seed=8)     # sizes the warm-up has not seen
     _, roof = edge_roofline(a4, g4, dev, "bf16")
-    # "fraction of the bf16 MFMA peak" is the wrong yardstick for a kernel whose own budget is matrix issue + vector issue
-    # that cannot overlap: beside it, the kernel's ISSUE-BOUND time from a committed rocprofv3 --pmc pass of this shape
+    # "fraction of the bf16 MFMA peak" is the wrong yardstick for this kernel: beside it, from committed rocprofv3 --pmc passes of
+    # this kernel at this shape (they cannot be taken inside this run): HBM-side traffic per launch, the kernel's ISSUE-BOUND
+    # time (matrix pipe + VALU issue that do not overlap, at the per-instruction issue costs the SQ_ACTIVE_INST counters give)
+    # and where its wave-cycles go (`stall_breakdown`)
     try:
         e = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))["configs[4] share, bf16 edge kernel: n_samples=256, n=27+-12"]
         cyc = e["issue_cycles_per_instruction"]
         plain = e["sq_insts_valu"] - e["sq_insts_mfma"] - e["sq_insts_valu_trans_f32"]
         cycles = e["sq_valu_mfma_busy_cycles"] + cyc["valu"] * plain + cyc["valu_trans_f32"] * e["sq_insts_valu_trans_f32"]
         bound_us = cycles / (1024 * 2.4e9) * 1e6
+        roof["traffic"] = e["traffic_bytes_corrected"]
+        roof["traffic_source"] = ("profiles/pmc_traffic.json (static: separate FETCH_SIZE / WRITE_SIZE passes, " + e["round"] + "; FETCH_SIZE x2 gfx950 "
+                                  "correction; algorithmic " + e["algorithmic_bytes"] + ")")
         roof["issue_bound"] = {"issue_bound_us": bound_us, "measured_us": roof["avg_launch_us"],
                                "frac": bound_us / roof["avg_launch_us"], "mfma_issue_us": e["sq_valu_mfma_busy_cycles"] / (1024 * 2.4e9) * 1e6,
                                "valu_issue_us": (cycles - e["sq_valu_mfma_busy_cycles"]) / (1024 * 2.4e9) * 1e6,
@@ -406,6 +411,7 @@ def config4_share(args, gsd, ctx, dev, fence):
                                "cycles_per_instruction": cyc,
                                "source": "profiles/pmc_traffic.json (static: separate rocprofv3 --pmc passes of this kernel at this shape, "
                                          + e["round"] + "); matrix and vector issue of a SIMD do not overlap in this kernel, so they add"}
+        roof["stall_breakdown"] = e["stall_breakdown"]
     except Exception:  # noqa: BLE001
         pass
     return {"workload": "configs[4] per-GPU share: n_samples=256, 27+-12 heavy atoms (ragged), fixed 8-atom fragment "

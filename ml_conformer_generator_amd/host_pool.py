@@ -250,21 +250,25 @@ class HostPool:
             fut, payload = job
             if not fut.set_running_or_notify_cancel():
                 continue
-            w = self._workers[k]
+            with self._lock:
+                w = self._workers[k] if k < len(self._workers) else None
             try:
                 if w is None:
                     raise EOFError("no worker")
                 reply = w.call(payload)
             except (EOFError, OSError, pickle.UnpicklingError, ValueError) as e:
                 pid = w.pid if w is not None else -1
-                fut.set_exception(HostPoolError(f"host worker {pid} died while it held a task ({type(e).__name__}: {e})"))
                 if w is not None:
                     w.stop(timeout=0.5)
-                try:
-                    self._workers[k] = _Worker(self._python, _worker_env())
-                    self.workers_replaced += 1
-                except Exception:  # noqa: BLE001 - keep serving: the next task fails loudly too
-                    self._workers[k] = None
+                # replace the worker BEFORE the caller learns of the failure (it may close the pool right away)
+                with self._lock:
+                    if not self._closed and k < len(self._workers):
+                        try:
+                            self._workers[k] = _Worker(self._python, _worker_env())
+                            self.workers_replaced += 1
+                        except Exception:  # noqa: BLE001 - keep serving: the next task fails loudly too
+                            self._workers[k] = None
+                fut.set_exception(HostPoolError(f"host worker {pid} died while it held a task ({type(e).__name__}: {e})"))
                 continue
             self.tasks_done += 1
             if reply[0]:
