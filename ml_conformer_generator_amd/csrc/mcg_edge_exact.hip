@@ -505,25 +505,17 @@ __global__ __launch_bounds__(256, 2) void k_edge_lds(EdgeArgs p) {
         // A-operand inputs of the NEXT group (or of the tail step) - ordinary loads, issued first
         f32x4 va[MT], vb[MT], wdv, w0v;
         if (q + 1 < NG) {
-#if defined(MCG_ABL_NOA32)       // (ablation switch: layer-1 inputs always those of group 1, from the L2-hot head of the rows)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
+#ifdef MCG_ABL_NOA32             // (ablation switch: layer-1 inputs always those of group 1, the L2-hot head of the rows.  Round 5:
+                                 //  4.461 vs 4.468 ms per call at configs[1] - this kernel, unlike the bf16 one, does not wait for them)
                 va[mt] = ld4(rs_pab, oa[mt], 64);
                 vb[mt] = ld4(rs_pab, ob[mt], 64);
-            }
-#elif defined(MCG_ABL_NOA32B)    // (ablation switch: gathered half from ONE row for every lane)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                va[mt] = ld4(rs_pab, oa[mt], 64 * (q + 1));
-                vb[mt] = ld4(rs_pab, oa[mt], 64 * (q + 1));
-            }
 #else
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
                 va[mt] = ld4(rs_pab, oa[mt], 64 * (q + 1));
                 vb[mt] = ld4(rs_pab, ob[mt], 64 * (q + 1));
-            }
 #endif
+            }
             wdv = ld4(rs_wd, ow, 64 * (q + 1));
             w0v = ld4(rs_w0, ow, 64 * (q + 1));
         } else {
