@@ -1977,3 +1977,21 @@ def test_bf16_mode_gathers_partial_sums_in_the_node_gemm(edm_sd):
         via2 = d.gcl_debug(plan, 1, via_combine, x0, x0)["h_out"]
         assert torch.equal(h_blk, via2), lds
     _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_GEMM_BF16_LDS, 0), "mcg_egnn_set_option")
+    # the LDS-staged kernel at shapes the automatic choice never gives it: a ragged last row block (M % 32 = 1, 31), fewer rows
+    # than one block, a single molecule - forced on against forced off, bit for bit
+    for small in ([17, 16], [31], [6, 7, 9, 11], [39] * 3 + [22]):
+        sz = torch.tensor(small)
+        Ns = int(sz.max())
+        nms = (torch.arange(Ns).unsqueeze(0) < sz.unsqueeze(1)).float().unsqueeze(2)
+        zs = (torch.randn(len(small), Ns, 11, generator=g) * nms).to(DEV)
+        cs = (torch.randn(len(small), 1, 3, generator=g).repeat(1, Ns, 1) * nms).to(DEV)
+        ts = torch.full((len(small),), 0.6, device=DEV)
+        res = []
+        for lds in (1, 2):
+            _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_GEMM_BF16_LDS, lds), "mcg_egnn_set_option")
+            launches()
+            res.append(d.run(d.plan(sz, Ns), ts, zs, cs).clone())
+            c = launches()
+            assert (int(c[1][7]) > 0) == (lds == 2), (small, lds, c)
+        assert torch.equal(res[0], res[1]), small
+    _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_GEMM_BF16_LDS, 0), "mcg_egnn_set_option")
