@@ -436,7 +436,9 @@ __global__ __launch_bounds__(MCG_LDSG_THREADS) void mcg_gemm_bf16_lds_kernel(Mcg
             for (int j = 0; j < S2F; ++j) { seg2_issue(j); seg2_park(j); }
         }
     }
-    __syncthreads();
+    // (not __syncthreads(): hipcc drains the vector-memory counter in front of it, which would wait out the weight ring, the
+    //  residual rows and the second segment's loads - exactly what is meant to stay in flight across this rendezvous)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     // ---- K loop: barrier-free, one wave = 2 x RN accumulators (transposed: weights as the MFMA A operand, see above)
     f32x4 acc[2][RN];
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(MCG_LDSG_THREADS) void mcg_gemm_bf16_lds_kernel(Mcg
         for (int r = 0; r < RING; ++r) load_w(r, b1 + r);          // the ring restarts at the segment boundary (its loads fly
 #pragma unroll                                                     //  while segment 2 is being parked)
         for (int j = 0; j < S2F; ++j) seg2_park(j);
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         k_loop(b1, blocks);
     } else {
         k_loop(0, blocks);

@@ -74,6 +74,15 @@ class GeneratedMolecule:
     def __repr__(self) -> str:
         return f"GeneratedMolecule(n_atoms={self.GetNumAtoms()}, valid={self.valid})"
 
+    def __eq__(self, other) -> bool:
+        """Value equality (atoms, coordinates, bond orders, validity) - whether or not the records are views of a batch."""
+        if not isinstance(other, GeneratedMolecule):
+            return NotImplemented
+        return (self.valid == other.valid and self.atomic_numbers == other.atomic_numbers
+                and torch.equal(self.coords, other.coords) and torch.equal(self.bond_orders, other.bond_orders))
+
+    __hash__ = None            # mutable value object, like the dataclass it replaced
+
     @property
     def symbols(self) -> List[str]:
         z2s = {z: ATOM_DECODER[i] for i, z in enumerate(ATOMIC_NUMBERS)}

@@ -377,6 +377,9 @@ def test_lazy_molecule_records_assemble_in_constant_python_work_per_molecule():
         assert torch.equal(m.bond_orders, bd[b, :k, :k]) and len(m.symbols) == k
     mols[3].valid = False                      # records stay independent of each other
     assert mols[4].valid == bool(v[4])
+    # value equality survives the lazy views (two assemblies of the same tensors compare equal, a changed flag does not)
+    again = molecules_from_tensors(x, el, bd, n, v)
+    assert mols[7] == again[7] and mols[3] != again[3] and mols[7] != mols[8]
 
 
 def test_atom_order_provider_plumbing_with_a_fake_provider():
