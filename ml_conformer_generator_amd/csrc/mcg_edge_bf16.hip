@@ -296,19 +296,20 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
     }
     // Operand addresses are (buffer descriptor in SGPRs) + (one 32-bit lane offset) + (scalar block offset): as
     // 64-bit per-lane pointers hipcc keeps ~20 VGPRs of addresses alive and the f32x6 variant spills.
-    // BLK (bf16 mode, round 5): the layer-1 inputs come in the BLOCKED layout Pab[part][k-block][atom][32] the bf16 first-layer
-    // GEMM writes for these plans (mcg_gemm.h: c_blocked) instead of row-major [atom][864].  A tile's 16 rows are (i, j .. j+15):
-    // row-major, the gathered half is a 64-byte piece of each of 16 lines 3 456 B apart, twice per block - and scattered
-    // loads are what this kernel waits for (ablations at the 256-ragged shape, profiles/round5_probes.txt: no layer-1 input loads
-    // 108 us, both halves broadcast-like 133, as built 143, both halves scattered 161; the 1.2 GB weight stream costs 16).  Blocked,
-    // consecutive atoms of one k-block are consecutive 128-byte lines: the same 16 rows are two contiguous KiB.  Measured:
-    // 4.50 -> 4.44 ms per denoiser call (same-run A/B) - the lines touched per instruction are the same 16, only closer together;
-    // staging the gathered half through LDS (LDS-DMA, whole lines once per workgroup) and relabelling k so that a lane group
-    // reads 64 contiguous bytes were built too and measured no gain / slower (profiles/round5_probes.txt).
-    const unsigned oa = BLK ? (unsigned)(vi * 32 + 8 * g) * 4u : (unsigned)(vi * (2 * HP) + 8 * g) * 4u;
-    const unsigned ob = BLK ? (unsigned)(vj * 32 + 8 * g) * 4u : (unsigned)(vj * (2 * HP) + HP + 8 * g) * 4u;
+    // BLK (bf16 mode, round 5): the layer-1 inputs come in the BLOCKED layout Pab[part][k-block][piece][atom][4] the bf16
+    // first-layer GEMM writes for these plans (mcg_gemm.h: c_blocked) instead of row-major [atom][864].  What this kernel waits for
+    // is vector-memory THROUGHPUT of the CU, and that is a matter of the per-lane address pattern, not of bytes
+    // (tools/native/gather_probe.hip, ns per instruction and wave at 8 waves per CU, L2-resident data): a contiguous KiB 66, one
+    // row for 16 lanes (Pa) 58, but 16 B of each of 16 rows x 4 slices - the A layout of the MFMA read row-major, lane 16 g + c =
+    // row c: ADJACENT LANES IN DIFFERENT ROWS - 224, wherever the rows are (3 456 B apart or adjacent: a first blocked layout
+    // [k-block][atom][32] measured 223).  The kernel's 28 such instructions per wave were 36 us of the memory pipeline per launch
+    // beside 38 for the weight stream (ablations, profiles/round5_probes.txt: 108 us without the layer-1 input loads, 143 with).
+    // Piece-major, the 16 rows (i, j .. j+15) of a tile put adjacent lanes on adjacent 16-byte pieces: 8 whole lines per instruction.
+    const unsigned oa = BLK ? (unsigned)(2 * g * p.M + vi) * 16u : (unsigned)(vi * (2 * HP) + 8 * g) * 4u;
+    const unsigned ob = BLK ? (unsigned)(2 * g * p.M + vj) * 16u : (unsigned)(vj * (2 * HP) + HP + 8 * g) * 4u;
     const int blk_stride = BLK ? p.M * 128 : 128;               // bytes from one k-block of a part to the next
     const int blk_part_b = BLK ? KB16 * p.M * 128 : 0;          // byte offset of the Pb part
+    const int blk_piece = BLK ? p.M * 16 : 16;                  // bytes from a lane's first 16-byte piece of a block to its second
     const __amdgpu_buffer_rsrc_t rs_pab = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pab), 0, 0xffffffff, 0x00020000);
     const float* wdp = wdl + 8 * g;
     const float* w0p = wdl + W64_KP + 8 * g;
@@ -343,8 +344,8 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
     auto load_a = [&](int kb, f32x4 (&v)[4]) {
         kb = kb < KB16 ? kb : KB16 - 1;
         const int so = blk_stride * kb;
-        v[0] = __builtin_bit_cast(f32x4, ld16(rs_pab, oa, so));  v[1] = __builtin_bit_cast(f32x4, ld16(rs_pab, oa, so + 16));
-        v[2] = __builtin_bit_cast(f32x4, ld16(rs_pab, ob, so + blk_part_b));  v[3] = __builtin_bit_cast(f32x4, ld16(rs_pab, ob, so + blk_part_b + 16));
+        v[0] = __builtin_bit_cast(f32x4, ld16(rs_pab, oa, so));  v[1] = __builtin_bit_cast(f32x4, ld16(rs_pab, oa, so + blk_piece));
+        v[2] = __builtin_bit_cast(f32x4, ld16(rs_pab, ob, so + blk_part_b));  v[3] = __builtin_bit_cast(f32x4, ld16(rs_pab, ob, so + blk_part_b + blk_piece));
     };
     // layer-1 finish + SiLU of my row tile for one k-block, written to ring half `half` as SPLIT bf16 parts
     auto agen_store = [&](const f32x4 (&v)[4], int kb, int half) {

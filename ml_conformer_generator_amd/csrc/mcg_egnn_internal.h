@@ -59,7 +59,7 @@ struct EdgeArgs {
     float* U;
     int n_full_wg;          // workgroups [0, n_full_wg) take four tiles each (LDS-staged body), the rest ONE tile (quarter-tile body)
     const float* Bp4;       // the same second-layer weights as B-pack4 (mcg_gemm.h): 16 B per lane and 16-k group
-    int pab_blocked;        // 64-row bf16 kernel: pab is [2 parts][14 k-blocks][M][32] (mcg_gemm.h c_blocked) instead of [M][864]
+    int pab_blocked;        // 64-row bf16 kernel: pab is [2 parts][14 k-blocks][8 pieces][M][4] (mcg_gemm.h c_blocked) instead of [M][864]
     int M;                  // atoms (rows of pab)
 };
 

@@ -45,18 +45,19 @@ struct McgGemmArgs {
     // x[v][0..2] += (side_u[s.x] + side_u[s.y] + side_u[s.z] + side_u[s.w]) / 100 - the coordinate update of the previous block (egnn.py:128-148)
     const float* side_u; const int4* side_slots; float* side_x; int side_M;
     int gemm_blocks;                        // workgroups of the GEMM proper (set by the launcher)
-    // bf16 kernels only: C is the BLOCKED layer-1 input layout of the bf16 edge kernel, C[part][k-block][row][32] with
-    // column = part * 432 + 32 * k-block + (0..31): the 16 rows (i, j .. j+15) of an edge tile then read their gathered half as
-    // contiguous KiB instead of one 64-byte piece from each of 16 rows 3 456 B apart (mcg_edge_bf16.hip, BLK)
+    // bf16 kernels only: C is the BLOCKED layer-1 input layout of the bf16 edge kernel, C[part][k-block][piece][row][4] with
+    // column = part * 432 + 32 * k-block + 4 * piece + (0..3): a 16-byte piece of 16 consecutive rows is 256 contiguous bytes,
+    // so the 16 rows (i, j .. j+15) of an edge tile read their gathered half with ADJACENT LANES ON ADJACENT ADDRESSES
+    // (mcg_edge_bf16.hip, BLK; tools/native/gather_probe.hip: 88 ns instead of 224 per instruction and wave)
     int c_blocked;
 };
 
 // address of C[row][16 * nt + 4 * g .. + 3] (nt = column tile): row-major, or the blocked layout above (27 column tiles per part,
-// 14 k-blocks of two tiles each; the odd half of the 14th block stays zero)
+// 14 k-blocks of two tiles = eight 4-column pieces each; the upper four pieces of the 14th block stay zero)
 __device__ __forceinline__ float* mcg_gemm_c_ptr(const McgGemmArgs& p, int orow, int nt, int g) {
     if (!p.c_blocked) return p.C + (size_t)orow * p.ldc + nt * 16 + 4 * g;
     const int part = nt >= 27 ? 1 : 0, ntp = nt - 27 * part;
-    return p.C + ((size_t)(part * 14 + (ntp >> 1)) * p.M + orow) * 32 + (ntp & 1) * 16 + 4 * g;
+    return p.C + ((size_t)((part * 14 + (ntp >> 1)) * 8 + (ntp & 1) * 4 + g) * p.M + orow) * 4;
 }
 
 // Side job of the fp32 node GEMM launches (workgroups beyond the GEMM's own grid): the coordinate update of the
@@ -347,70 +348,77 @@ __global__ __launch_bounds__(MCG_LDSG_THREADS) void mcg_gemm_bf16_lds_kernel(Mcg
 #pragma unroll
     for (int m = 0; m < 2; ++m) { const int r = row0 + 16 * m + c; rr[m] = r < p.M ? r : p.M - 1; }
 
-    // ---- park segment 1 of the activation block: fragment f = 2 * kb + m (row tile m of k-block kb); a wave takes the
-    //      fragment pairs wid, wid + 9, ... - both loads of a pair in flight together
+    // ---- park the activation block.  LOADS ARE COALESCED, the MFMA layout is made on the way into LDS: read the way the
+    //      fragments want it (lane 16 g + c = row c, slice g) adjacent lanes sit in different rows and an instruction costs the
+    //      memory pipeline 224 ns per wave instead of 88 (tools/native/gather_probe.hip).  So lane l of a load takes the 16-byte
+    //      piece l % 8 of row 8 i + l / 8 (i = 0..3: a quarter of the 32 rows; 8 whole 128-byte lines per instruction), rounds its
+    //      four values to bf16 and writes those 8 bytes where lane 16 (piece / 2) + row % 16 of fragment (k-block, row / 16) will
+    //      read its ds_read_b128.  A wave owns the k-blocks wid, wid + 9 of each segment.
+    const int prow = lane >> 3, piece = lane & 7;
+    int qrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int r = row0 + 8 * i + prow; qrow[i] = r < p.M ? r : p.M - 1; }
+    auto park_quarter = [&](int frag_kb, int i, f32x4 v, int k0, int K) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (k0 + e >= K) v[e] = 0.f;                            // k beyond the segment: zero (the packed weights are zero there too)
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        const bf16x4 h4 = (bf16x4){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        char* dst = reinterpret_cast<char*>(sA) + (((2 * frag_kb + (i >> 1)) * 64 + 16 * (piece >> 1) + 8 * (i & 1) + prow) * 16 + (piece & 1) * 8);
+        *reinterpret_cast<bf16x4*>(dst) = h4;
+    };
     {
         const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A1), 0, 0xffffffff, 0x00020000);
-        for (int f0 = wid * 2; f0 < 2 * b1; f0 += 2 * MCG_LDSG_WAVES) {
-            f32x4 v[2][2];
+        for (int kb = wid; kb < b1; kb += MCG_LDSG_WAVES) {
+            f32x4 v[4];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int f = f0 + q, kb = f >> 1, m = f & 1;
-                const unsigned off = (unsigned)(rr[m] * p.lda1 + 32 * kb + 8 * g) * 4u;
-                v[q][0] = __builtin_bit_cast(f32x4, ld(rs_a1, off, 0));
-                v[q][1] = __builtin_bit_cast(f32x4, ld(rs_a1, off, 16));
-            }
+            for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(f32x4, ld(rs_a1, (unsigned)(qrow[i] * p.lda1 + 32 * kb + 4 * piece) * 4u, 0));
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int f = f0 + q, kb = f >> 1;
-                const int k0 = 32 * kb + 8 * g;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {                       // k beyond the segment: zero (the packed weights are zero there too)
-                    if (k0 + e >= p.K1) v[q][0][e] = 0.f;
-                    if (k0 + 4 + e >= p.K1) v[q][1][e] = 0.f;
-                }
-                sA[f * 64 + lane] = mcg_pack_bf16(v[q][0], v[q][1]);
-            }
+            for (int i = 0; i < 4; ++i) park_quarter(kb, i, v[i], 32 * kb + 4 * piece, p.K1);
         }
     }
     // ---- segment 2: plain rows, or the sum of an atom's <= GATHER partial rows / 100 (slot order, then mcg_div100, then the
     //      bf16 rounding - exactly the A-loader of mcg_gemm_bf16_kernel).  Its loads are ISSUED here, in front of the first
-    //      barrier, and consumed behind the K loop over segment 1 (their latency hides under it); a wave owns the fragments
-    //      wid, wid + 9, wid + 18, wid + 27 (2 * b2 <= 28 of them)
+    //      barrier, and consumed behind the K loop over segment 1 (their latency hides under it)
     constexpr int NS = GATHER >= 2 ? GATHER : 1;
-    constexpr int S2F = SEG2 ? 4 : 0;
-    f32x4 s2[SEG2 ? 4 : 1][NS][2];
+    constexpr int S2P = SEG2 ? 2 : 0;                      // k-blocks of segment 2 per wave (b2 <= 14 over 9 waves)
+    f32x4 s2[SEG2 ? 2 : 1][4][NS];
     const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A2 ? p.A2 : p.A1), 0, 0xffffffff, 0x00020000);
-    auto seg2_issue = [&](int j) {
-        int f = wid + j * MCG_LDSG_WAVES;
-        f = f < 2 * b2 ? f : 2 * b2 - 1;                                // (clamped: unconditional loads, the store is predicated)
-        const int kb = f >> 1, m = f & 1;
-        int rows[4] = {rr[m], rr[m], rr[m], rr[m]};
-        if constexpr (GATHER >= 2) { const int4 sl = p.a2_rows[rr[m]]; rows[0] = sl.x; rows[1] = sl.y; rows[2] = sl.z; rows[3] = sl.w; }
+    int srow[4][NS];
 #pragma unroll
-        for (int q = 0; q < NS; ++q) {
-            const unsigned off = (unsigned)(rows[q] * p.lda2 + 32 * kb + 8 * g) * 4u;
-            s2[j][q][0] = __builtin_bit_cast(f32x4, ld(rs_a2, off, 0));
-            s2[j][q][1] = __builtin_bit_cast(f32x4, ld(rs_a2, off, 16));
+    for (int i = 0; i < 4; ++i) {
+        if constexpr (GATHER >= 2) {
+            const int4 sl = (SEG2 && p.a2_rows) ? p.a2_rows[qrow[i]] : (int4){0, 0, 0, 0};
+            const int rows[4] = {sl.x, sl.y, sl.z, sl.w};
+#pragma unroll
+            for (int q = 0; q < NS; ++q) srow[i][q] = rows[q];
+        } else {
+            srow[i][0] = qrow[i];
         }
+    }
+    auto seg2_issue = [&](int j) {
+        int kb = wid + j * MCG_LDSG_WAVES;
+        kb = kb < b2 ? kb : b2 - 1;                                     // (clamped: unconditional loads, the park is predicated)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < NS; ++q)
+                s2[j][i][q] = __builtin_bit_cast(f32x4, ld(rs_a2, (unsigned)(srow[i][q] * p.lda2 + 32 * kb + 4 * piece) * 4u, 0));
     };
     auto seg2_park = [&](int j) {
-        const int f = wid + j * MCG_LDSG_WAVES;
-        if (f >= 2 * b2) return;
-        const int k0 = 32 * (f >> 1) + 8 * g;
-        f32x4 lo = s2[j][0][0], hi = s2[j][0][1];
-        if constexpr (GATHER >= 2) {
+        const int kb = wid + j * MCG_LDSG_WAVES;
+        if (kb >= b2) return;
 #pragma unroll
-            for (int q = 1; q < NS; ++q) { lo += s2[j][q][0]; hi += s2[j][q][1]; }
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v = s2[j][i][0];
+            if constexpr (GATHER >= 2) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { lo[e] = mcg_div100(lo[e]); hi[e] = mcg_div100(hi[e]); }
+                for (int q = 1; q < NS; ++q) v += s2[j][i][q];          // slot order = unit order: fixed, deterministic
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = mcg_div100(v[e]);   // the aggregate's / normalization_factor (egnn.py:435)
+            }
+            park_quarter(b1 + kb, i, v, 32 * kb + 4 * piece, p.K2);
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (k0 + e >= p.K2) lo[e] = 0.f;
-            if (k0 + 4 + e >= p.K2) hi[e] = 0.f;
-        }
-        sA[(2 * b1 + f) * 64 + lane] = mcg_pack_bf16(lo, hi);
     };
     // the residual rows (W4: h) are requested here, a whole K loop ahead of their use
     f32x4 eres[RESID ? 2 : 1][RN];
@@ -430,10 +438,10 @@ __global__ __launch_bounds__(MCG_LDSG_THREADS) void mcg_gemm_bf16_lds_kernel(Mcg
     if (SEG2 && b2 > 0) {
         if constexpr (OVERLAP2) {
 #pragma unroll
-            for (int j = 0; j < S2F; ++j) seg2_issue(j);
+            for (int j = 0; j < S2P; ++j) seg2_issue(j);
         } else {
 #pragma unroll
-            for (int j = 0; j < S2F; ++j) { seg2_issue(j); seg2_park(j); }
+            for (int j = 0; j < S2P; ++j) { seg2_issue(j); seg2_park(j); }
         }
     }
     // (not __syncthreads(): hipcc drains the vector-memory counter in front of it, which would wait out the weight ring, the
@@ -475,7 +483,7 @@ __global__ __launch_bounds__(MCG_LDSG_THREADS) void mcg_gemm_bf16_lds_kernel(Mcg
 #pragma unroll
         for (int r = 0; r < RING; ++r) load_w(r, b1 + r);          // the ring restarts at the segment boundary (its loads fly
 #pragma unroll                                                     //  while segment 2 is being parked)
-        for (int j = 0; j < S2F; ++j) seg2_park(j);
+        for (int j = 0; j < S2P; ++j) seg2_park(j);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         k_loop(b1, blocks);
     } else {
