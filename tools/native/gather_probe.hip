@@ -6,6 +6,11 @@
 //   C  blocked     lane (c, g) reads 16 B at (r0 + c) * 128 + 32 g                        (Pb, blocked: 16 adjacent lines)
 //   D  broadcast   lane (c, g) reads 16 B at row r0 * 3456 + 32 g                         (Pa: one line, 16 lanes per address)
 //   E  permuted    lane l reads 16 B at (r0 + l / 8) * 128 + 16 (l % 8)                   (blocked, whole lines: 8 lines)
+//   F  rows8x128   lane l reads 16 B at (r0 + l / 8) * 1680 + 128 d + 16 (l % 8)          (node features, 420 floats per row: 128 B of 8 rows,
+//                                                                                           not line-aligned)
+//   G  rows16x64   lane l reads 16 B at (r0 + l / 4) * 1680 + 128 d + 64 h + 16 (l % 4)   (64 B of 16 rows)
+//   H  rows16x16   lane (c, g) reads 16 B at (r0 + c) * 1680 + 64 q + 16 g                (the fp32 node GEMMs' activation fragment today)
+//   I  rows8x128a  as F with rows padded to 1792 B (line-aligned)
 // Prints ns per instruction and wave, and the implied instructions per microsecond and CU.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -31,7 +36,11 @@ __global__ __launch_bounds__(256) void k_probe(const float* __restrict__ buf, fl
             else if (PAT == 1) off = (unsigned)((rr + c) * 3456 + kb * 128 + g * 32);
             else if (PAT == 2) off = (unsigned)(kb * n_rows * 128 + (rr + c) * 128 + g * 32);
             else if (PAT == 3) off = (unsigned)(rr * 3456 + kb * 128 + g * 32);
-            else off = (unsigned)(kb * n_rows * 128 + (rr + (lane >> 3)) * 128 + (lane & 7) * 16);
+            else if (PAT == 4) off = (unsigned)(kb * n_rows * 128 + (rr + (lane >> 3)) * 128 + (lane & 7) * 16);
+            else if (PAT == 5) off = (unsigned)((rr + (lane >> 3)) * 1680 + (kb % 13) * 128 + (lane & 7) * 16);
+            else if (PAT == 6) off = (unsigned)((rr + (lane >> 2)) * 1680 + (kb % 13) * 128 + (u & 1) * 64 + (lane & 3) * 16);
+            else if (PAT == 7) off = (unsigned)((rr + c) * 1680 + (kb % 13) * 128 + (u & 1) * 64 + g * 16);
+            else off = (unsigned)((rr + (lane >> 3)) * 1792 + (kb % 13) * 128 + (lane & 7) * 16);
             const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
             acc += v;
         }
@@ -62,6 +71,8 @@ int main() {
     for (int rep = 0; rep < 2; ++rep) {
         run<0>("coalesced", buf, out, n_rows); run<1>("rowgather", buf, out, n_rows); run<2>("blocked", buf, out, n_rows);
         run<3>("broadcast", buf, out, n_rows); run<4>("permuted", buf, out, n_rows);
+        run<5>("rows8x128", buf, out, n_rows); run<6>("rows16x64", buf, out, n_rows); run<7>("rows16x16", buf, out, n_rows);
+        run<8>("rows8x128a", buf, out, n_rows);
     }
     return 0;
 }
