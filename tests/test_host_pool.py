@@ -103,7 +103,17 @@ def test_shared_pool_and_chunking_rules():
     assert isinstance(HP.shared_pool(0), HP.SerialExecutor)
     a, b = HP.shared_pool(3), HP.shared_pool(3)
     assert a is b and a.n_workers == 3 and a.worker_pids() == []           # lazily started: nothing spawned yet
-    assert HP.default_workers() == min(32, os.cpu_count())
+    saved = os.environ.pop("LOCAL_WORLD_SIZE", None)
+    try:
+        assert HP.default_workers() == min(32, os.cpu_count())
+        os.environ["LOCAL_WORLD_SIZE"] = "8"              # one process per GPU: the node's cores are shared between its ranks
+        assert HP.default_workers() == max(1, min(32, os.cpu_count() // 8))
+        os.environ["LOCAL_WORLD_SIZE"] = "not a number"
+        assert HP.default_workers() == min(32, os.cpu_count())
+    finally:
+        os.environ.pop("LOCAL_WORLD_SIZE", None)
+        if saved is not None:
+            os.environ["LOCAL_WORLD_SIZE"] = saved
     assert HP.chunk_bounds(10, 4) == [(0, 4), (4, 8), (8, 10)] and HP.chunk_bounds(0, 4) == []
     assert HP.task_chunk(64, 32) == 1 and HP.task_chunk(2048, 32) == 8 and HP.task_chunk(256, 8) == 8
     assert HP.task_chunk(5, 0) == 5 and HP.task_chunk(0, 4) == 1
