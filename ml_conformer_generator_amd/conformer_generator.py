@@ -18,7 +18,7 @@ forced by the scope of this build:
     absent here); without RDKit it returns `GeneratedMolecule` records filtered by the labelled
     valence / single-fragment PROXY, and `optimise_geometry=True` cannot be honoured (one
     warning per process).  An RDKit Mol is accepted as reference conformer / fixed fragment;
-  * `n_host_workers` (default min(32, host cores); 0 = serial): the two RDKit stages - canonical order + connectivity
+  * `n_host_workers` (default min(32, this rank's share of the host cores); 0 = serial): the two RDKit stages - canonical order + connectivity
     before the GCN, `redefine_bonds` + `standardize_mol` (MMFF) behind it - are fanned out over a pool of fresh worker
     processes (`host_pool.py`) and pipelined against the GPU per group of molecules; the reference runs them one molecule
     at a time on the calling thread (conformer_generator.py:343-366).  Same per-molecule code, same results, same order;
