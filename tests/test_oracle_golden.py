@@ -1,5 +1,7 @@
 """Pin the CPU oracle against outputs of the reference itself (tests/golden, made by
 tools/make_golden.py).  CPU-only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -124,14 +126,38 @@ def test_sampler_at_the_judged_step_counts():
     g = load_golden("inpaint_T250_rs1_b2.npz")
     assert float(g["one_ulp_context_rel_dev"]) < 1e-5
     nm = g["node_mask"]
+    # 501 denoiser calls are ~35 s of an idle 8-core host and many minutes of a contended one: by default the replay stops
+    # after the 3rd kept latent (151 sampler steps = 152 calls of the resampling loop); MCG_ORACLE_FULL=1 runs all 500 steps
+    # and checks the decoded x / h as well.  (The HIP path is compared with this fixture at full length either way:
+    # tests/test_hip_parity.py::test_sampler_at_the_judged_step_counts_vs_reference_golden.)
+    full = os.environ.get("MCG_ORACLE_FULL", "0") == "1"
+    idx = g["z_trace_index"].long()
+    keep = idx.numel() if full else 3
+    stop_after = None if full else int(idx[keep - 1]) + 1
+
+    class _Enough(Exception):
+        pass
+
     s = DO.SamplerOracle(sd_for(g), int(g["T"]), noise_fn=TapeNoise(g["noise"]))
-    s.trace = []
-    x, h = s.inpaint(nm, edge_mask_of(nm), g["context"], g["z_known"], g["fixed_mask"], 1, 3)
-    assert s.noise_fn.pos == g["noise"].numel() and len(s.trace) == int(g["n_sampler_steps"]) == 500
-    zt = torch.stack(s.trace)[g["z_trace_index"].long()]
-    assert traj_violation(zt, g["z_trace"], rel=2e-5) <= 1.0, traj_violation(zt, g["z_trace"], rel=2e-5)
-    assert violation(x, g["x"]) <= 1.0
-    assert torch.equal(h.to(torch.int64), g["h"].to(torch.int64))
+
+    class _Trace(list):
+        def append(self, z):
+            super().append(z)
+            if stop_after is not None and len(self) >= stop_after:
+                raise _Enough
+
+    s.trace = _Trace()
+    try:
+        x, h = s.inpaint(nm, edge_mask_of(nm), g["context"], g["z_known"], g["fixed_mask"], 1, 3)
+    except _Enough:
+        x = h = None
+    assert (x is not None) == full
+    zt = torch.stack(list(s.trace))[idx[:keep]]
+    assert traj_violation(zt, g["z_trace"][:keep], rel=2e-5) <= 1.0, traj_violation(zt, g["z_trace"][:keep], rel=2e-5)
+    if full:
+        assert s.noise_fn.pos == g["noise"].numel() and len(s.trace) == int(g["n_sampler_steps"]) == 500
+        assert violation(x, g["x"]) <= 1.0
+        assert torch.equal(h.to(torch.int64), g["h"].to(torch.int64))
 
 
 def test_merge_fragments():
