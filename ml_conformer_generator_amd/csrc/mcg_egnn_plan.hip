@@ -190,12 +190,16 @@ static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, c
     // kernels) keep round 1's rule; the split-operand modes' host mirror asks for two ranges explicitly (f32x6 at
     // config 2: 3.53 -> 3.18 ms per call - their edge kernel is short against the node phase).  Round 5, 64-row bf16 plans with
     // the LDS-staged node GEMM, ms per call with 1 / 2 / 3 ranges at the 256-ragged shape (12 020 tiles): 4.60 / 4.63 / 5.45
-    // (round 4, 32-row GEMM: 5.55 / 5.25 / 5.74) - the node phase no longer needs another range's edge kernel to hide under:
-    // one range up to 16 384 tiles.
+    // (round 4, 32-row GEMM: 5.55 / 5.25 / 5.74).  With the final round-5 kernels (blocked layer-1 inputs, single-product
+    // aggregation) the same shape runs 4.36 / 4.08 / 5.02, and 27-atom batches of 96 / 128 / 160 / 192 molecules 2.25 / 2.26,
+    // 2.54 / 2.73, 2.98 / 3.16, 3.51 / 3.30 with 1 / 2 ranges (tools/ab_bf16_ranges.sh): two ranges pay exactly when each
+    // half still has the 80 row blocks of 32 atoms from which the bf16 node GEMMs take the LDS-staged kernel
+    // (MCG_LDSG_MIN_ROWBLOCKS, mcg_gemm.h) - 5 120 atoms in all.
+    constexpr int BF16_TWO_RANGES_FROM_ATOMS = 2 * 80 * 32;
     int parts = 1;
     if (n_ranges > 0) parts = n_ranges;
     else if (p->MT == 1) parts = p->n_mtiles < 3600 ? 1 : p->n_mtiles < 5200 ? 2 : p->n_mtiles < 14000 ? 3 : 4;
-    else parts = p->n_mtiles >= 16384 ? 2 : 1;
+    else parts = p->M >= BF16_TWO_RANGES_FROM_ATOMS ? 2 : 1;
     if (parts < 2 || B < 2 * parts || p->n_rows < 4096) return MCG_OK;
     const std::vector<int> cuts = mcg_plan_range_cuts(B, n_nodes_host, parts);     // host-only, sanitizer-covered
     for (size_t k = 0; k + 1 < cuts.size(); ++k) {
