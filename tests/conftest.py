@@ -1,6 +1,13 @@
 import os
 import sys
 
+# The CPU oracle runs hundreds of small torch ops on 8 OpenMP threads.  libgomp's default wait policy spins ~300 000
+# iterations at every barrier; on a host whose cores are shared (hypervisor steal, other jobs) a spinning thread burns the
+# time slice the thread it waits for needs: the oracle sampler tests were measured 45x slower with six busy processes
+# beside them (183 s instead of 4 s), 7x with a short spin (30 s).  Costs ~15 % on an idle host.  Must be set before
+# libgomp is loaded, i.e. before `import torch`; an explicit setting in the environment wins.
+os.environ.setdefault("GOMP_SPINCOUNT", "3000")
+
 import numpy as np
 import pytest
 import torch
