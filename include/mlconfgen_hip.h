@@ -55,7 +55,7 @@ int mcg_egnn_set_precision(mcg_egnn* m, int mode);
  *   MCG_OPT_X6_GEMM     [1]  f32x6 mode: 1 = node-side GEMMs on the split-operand kernel too, 0 = exact fp32 GEMMs
  *   MCG_OPT_GEMM_RN     [0]  wave tile width (column tiles) of the 32-row node GEMM kernel: 0 = cost model, 1..3
  *   MCG_OPT_GEMM_X6_RN  [0]  same for the split-operand GEMM kernel
- *   MCG_OPT_GEMM_BF16_LDS [0] bf16 mode: 0 = the LDS-staged 9-wave node GEMM from ~3 000 atoms on, 1 = never (32-row kernel),
+ *   MCG_OPT_GEMM_BF16_LDS [0] bf16 mode: 0 = the LDS-staged 9-wave node GEMM from 80 row blocks (2 560 atoms) on, 1 = never (32-row kernel),
  *                            2 = whenever its shape limits allow (results are bit-identical either way) */
 enum { MCG_OPT_X6_GEMM = 1, MCG_OPT_GEMM_RN = 2, MCG_OPT_GEMM_X6_RN = 3, MCG_OPT_GEMM_BF16_LDS = 4 };
 /* Both setters may be called at any time between denoiser calls: a plan that has already captured its launches as a HIP

@@ -3,15 +3,27 @@ run BY FILE PATH so that the package's `__init__` (torch, the HIP library) is ne
 standard library, whatever the task file imports (numpy + RDKit for `_rdkit_tasks.py`) and nothing else - no GPU context,
 no fork of a process that has one.
 
-Protocol (pickle frames over two dedicated pipes; stdout is pointed at stderr so a chatty task cannot corrupt a frame):
-    parent -> worker   (task_file, func_name, items, args)       EOF = shut down
-    worker -> parent   (True, results) | (False, exception, traceback_text)
+`sys.path[0]` - this package's own directory, because the script is run by path - is REMOVED first: left in place, the
+package's `config.py`, `distributed.py`, `schedule.py`, `weights.py` ... would shadow top-level modules of the same name
+for everything a task imports (`import distributed` inside a caller's task file would pull in torch and this package).
+
+Protocol (two dedicated pipes; stdout is pointed at stderr so a chatty task cannot corrupt a frame):
+    parent -> worker   pickle frame (task_file, func_name, items, args)       EOF = shut down
+    worker -> parent   8-byte little-endian length + pickle of (True, results) | (False, exception, traceback_text)
+                       (length-prefixed so that the parent can read it under a deadline, `host_pool._Worker.call`)
+An exception whose class lives in a task file loaded by path (module `_mcg_host_task_<n>`: the parent cannot import it)
+travels as a RuntimeError naming the original type.
 """
-import importlib.util
 import os
-import pickle
 import sys
-import traceback
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:] = [p for p in sys.path if os.path.abspath(p or os.getcwd()) != _HERE]
+
+import importlib.util  # noqa: E402
+import pickle  # noqa: E402
+import struct  # noqa: E402
+import traceback  # noqa: E402
 
 _MODULES = {}
 
@@ -32,6 +44,11 @@ def main() -> int:
     rd = os.fdopen(int(sys.argv[1]), "rb")
     wr = os.fdopen(int(sys.argv[2]), "wb")
     sys.stdout = sys.stderr
+    for path in sys.argv[3:]:            # preload (host_pool.prestart): import the task files now, while the parent is busy elsewhere
+        try:
+            _load(path)
+        except BaseException:  # noqa: BLE001 - the task that needs the file reports the error properly
+            _MODULES.pop(path, None)
     while True:
         try:
             msg = pickle.load(rd)
@@ -44,13 +61,16 @@ def main() -> int:
         except BaseException as e:  # noqa: BLE001 - reported to the parent, which re-raises it in the caller
             tb = traceback.format_exc()
             try:
+                if (type(e).__module__ or "").startswith("_mcg_host_task_"):
+                    raise TypeError("exception class defined in a by-path task module")      # the parent cannot import it
                 data = pickle.dumps((False, e, tb), protocol=pickle.HIGHEST_PROTOCOL)
-            except Exception:  # noqa: BLE001 - an exception that does not pickle
+                pickle.loads(data)              # (an exception with a non-trivial __init__ pickles but does not rebuild)
+            except Exception:  # noqa: BLE001 - an exception that does not make the trip
                 data = pickle.dumps((False, RuntimeError(f"{type(e).__name__}: {e}"), tb), protocol=pickle.HIGHEST_PROTOCOL)
             if isinstance(e, (KeyboardInterrupt, SystemExit)):
-                wr.write(data); wr.flush()
+                wr.write(struct.pack("<Q", len(data)) + data); wr.flush()
                 return 1
-        wr.write(data)
+        wr.write(struct.pack("<Q", len(data)) + data)
         wr.flush()
 
 

@@ -58,7 +58,8 @@ def order_one(atomic_numbers, coords, z2symbol):
 
 
 def order_chunk(items, z2symbol):
-    return [order_one(z, c, z2symbol) if len(z) > 0 else (None, None) for z, c in items]
+    # an EMPTY molecule cannot be built (`MolFromXYZBlock` of "0 atoms" is None: dropped) - not "built, no connectivity"
+    return [order_one(z, c, z2symbol) if len(z) > 0 else None for z, c in items]
 
 
 # ------------------------------------------------------------------------------------------- behind the GCN

@@ -22,6 +22,12 @@ forced by the scope of this build:
     before the GCN, `redefine_bonds` + `standardize_mol` (MMFF) behind it - are fanned out over a pool of fresh worker
     processes (`host_pool.py`) and pipelined against the GPU per group of molecules; the reference runs them one molecule
     at a time on the calling thread (conformer_generator.py:343-366).  Same per-molecule code, same results, same order;
+    the workers are started in the background BEFORE the sampler is launched, and every task has a deadline
+    (`task_timeout_s`, default 60 s per chunk of <= 8 molecules; None = none): a worker stuck inside RDKit is killed and
+    replaced and its molecules are dropped like any other the gate rejects (utils/standardizer.py:108-109), with a warning;
+  * `cpu_affinity` (default None = leave the process alone; "auto" = pin this process - torch's threads and the host
+    pool's workers, which inherit the mask - to the cores of its GPU's NUMA node, shared between the ranks of the node:
+    `affinity.py`, sysfs only, no HIP call; or an explicit list of cores);
   * `generate_conformers_sharded(...)`: the same call, batch-sharded over the ranks of an
     initialised `torch.distributed` group (one process per GPU, one gather at the end).
 """
@@ -93,7 +99,7 @@ class MLConformerGenerator(torch.nn.Module):
                  edm_weights: Union[str, dict] = "./edm_moi_chembl_15_39.pt",
                  adj_mat_seer_weights: Union[str, dict] = "./adj_mat_seer_chembl_15_39.pt",
                  compute_dtype: str = "f32", atom_order_provider="auto", n_host_workers: Optional[int] = None,
-                 finisher="auto"):
+                 finisher="auto", task_timeout_s: Optional[float] = host_pool.DEFAULT_TASK_TIMEOUT_S, cpu_affinity=None):
         super().__init__()
         _lib.lib()       # fail loudly if the HIP library is not built
         device = torch.device("cuda:0" if device is None else device)
@@ -103,6 +109,14 @@ class MLConformerGenerator(torch.nn.Module):
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = device
+        # placement first: threads and worker processes created from here on inherit it (affinity.py; sysfs only)
+        self.cpu_affinity = None
+        if cpu_affinity is not None:
+            from . import affinity
+            cpus = affinity.rank_cpus(int(os.environ.get("LOCAL_RANK", "0") or 0),
+                                      int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1),
+                                      device.index) if cpu_affinity == "auto" else list(cpu_affinity)
+            self.cpu_affinity = affinity.pin(cpus)
         self.dimension = dimension
         self.context_norms = {k: torch.tensor(v) for k, v in context_norms.items()}
         self.atom_decoder = atom_decoder
@@ -126,6 +140,9 @@ class MLConformerGenerator(torch.nn.Module):
         self.finisher = ("rdkit" if HAVE_RDKIT else None) if finisher == "auto" else finisher
         # host fan-out of the two RDKit stages (host_pool.py): worker PROCESSES, created at first use; 0 = this thread
         self.n_host_workers = host_pool.default_workers() if n_host_workers is None else int(n_host_workers)
+        if self.cpu_affinity and n_host_workers is None:
+            self.n_host_workers = max(1, min(self.n_host_workers, len(self.cpu_affinity)))     # one worker per pinned core at most
+        self.task_timeout_s = task_timeout_s      # deadline of one host task (a chunk of molecules); None = none
         self._finish_stage = None    # rdkit_finish.FinishStage of the shard generated last (consumed by the callers)
         self.last_host_order_ms = None    # wall time from the first order task to the last group's hand-off launch
         self.last_host_finish_ms = None   # wall time spent waiting for finish results after the last group was submitted
@@ -231,9 +248,9 @@ class MLConformerGenerator(torch.nn.Module):
             "Either a reference RDkit Mol object or context as torch.Tensor should be provided for generation.")
 
     def _executor(self):
-        """Where the poolable host tasks run: the process-wide `HostPool` with `n_host_workers` workers (created at the
-        first submit), or this thread."""
-        return host_pool.shared_pool(self.n_host_workers)
+        """Where the poolable host tasks run: the process-wide `HostPool` with `n_host_workers` workers and this generator's
+        task deadline (workers created at the first submit or by `prestart`), or this thread."""
+        return host_pool.shared_pool(self.n_host_workers, getattr(self, "task_timeout_s", host_pool.DEFAULT_TASK_TIMEOUT_S))
 
     def _generate_shard(self, ref_context, ref_n_atoms: int, variance: int, sizes: Optional[torch.Tensor],
                         n_samples: int, resample_steps, fixed_fragment, inertial_fragment_matching, blend_power,
@@ -252,7 +269,21 @@ class MLConformerGenerator(torch.nn.Module):
         dev = self.device
         self._finish_stage = None
         self.last_host_order_ms = self.last_host_finish_ms = None
+        provider, finisher = self.atom_order_provider, getattr(self, "finisher", None)
+        staged = provider is not None or finisher is not None
+        executor = self._executor() if staged else None
+        if executor is not None:
+            # worker start-up (~0.3 s for 32 interpreters, plus `import rdkit` in each) hides under the sampler launched below
+            tasks = [rdkit_order.provider_task(provider)[0]] if provider is not None and rdkit_order.provider_task(provider) else []
+            if finisher == "rdkit":
+                tasks.append(host_pool.FINISH_TASK)
+            elif isinstance(finisher, host_pool.TaskRef):
+                tasks.append(finisher)
+            executor.prestart(tasks)
         if n_samples == 0:
+            if finisher is not None:      # an empty shard still takes part in the object gather of the finished molecules
+                from . import rdkit_finish
+                self._finish_stage = rdkit_finish.FinishStage(finisher, optimise_geometry, executor)
             return dict(x=torch.zeros(0, N, 3, device=dev), elements=torch.zeros(0, D, dtype=torch.int8, device=dev),
                         bond=torch.zeros(0, D, D, dtype=torch.int8, device=dev),
                         n_nodes=torch.zeros(0, dtype=torch.int32, device=dev),
@@ -263,10 +294,7 @@ class MLConformerGenerator(torch.nn.Module):
             inertial_fragment_matching=inertial_fragment_matching, blend_power=blend_power,
             ifm_diffusion_level=ifm_diffusion_level, sizes=sizes)
         n_nodes = node_mask.sum(1).reshape(-1).to(torch.long)
-        provider, finisher = self.atom_order_provider, getattr(self, "finisher", None)
-        staged = provider is not None or finisher is not None
         groups = rdkit_order.launch_groups(n_samples) if staged else [(0, n_samples)]
-        executor = self._executor() if staged else None
         t0 = time.perf_counter()
         # host: RDKit's (or the caller's) order + connectivity - every task of the batch goes out now
         stage = rdkit_order.OrderStage(provider, x, h, n_nodes, executor, groups) if provider is not None else None
@@ -357,11 +385,25 @@ class MLConformerGenerator(torch.nn.Module):
         lo_n = max(ref_n_atoms - variance, self.min_n_nodes)
         hi_n = min(ref_n_atoms + variance, self.max_n_nodes)
         self._finish_stage = None
+        # decided from the configuration, not from what this rank's shard happened to produce: every rank takes the same
+        # path through the collectives (an EMPTY shard has no stage of its own making)
+        finishing = getattr(self, "finisher", None) is not None
+        finished: List = [None]
 
         def run_shard(sizes_shard, index):
-            return self._generate_shard(ref_context, ref_n_atoms, variance, sizes_shard, int(index.numel()), resample_steps,
-                                        fixed_fragment, inertial_fragment_matching, blend_power, ifm_diffusion_level,
-                                        optimise_geometry)
+            res = self._generate_shard(ref_context, ref_n_atoms, variance, sizes_shard, int(index.numel()), resample_steps,
+                                       fixed_fragment, inertial_fragment_matching, blend_power, ifm_diffusion_level,
+                                       optimise_geometry)
+            if finishing:
+                # collected HERE, in front of the status exchange: a finish that raises on one rank (a dead worker, a custom
+                # finisher's exception, a result-count mismatch) makes EVERY rank raise ShardError instead of leaving the
+                # others parked in the object gather
+                stage, self._finish_stage = getattr(self, "_finish_stage", None), None
+                done = self._collect_finish(stage) if stage is not None else []
+                if len(done) != int(index.numel()):
+                    raise ValueError(f"the finish returned {len(done)} results for a shard of {int(index.numel())}")
+                finished[0] = done
+            return res
 
         def seed_device(s):
             self.last_noise_seed = s          # this rank's noise stream (base seed + rank)
@@ -372,11 +414,11 @@ class MLConformerGenerator(torch.nn.Module):
         dst = 0 if gather == "rank0" else None
         _, res, shards = mcg_dist.sharded_generate(
             n_samples, lambda: mcg_dist.draw_global_sizes(n_samples, lo_n, hi_n, group), run_shard, group=group,
-            seed=seed, seed_fn=seed_device, gather_dst=dst, balance=balance)
+            seed=seed, seed_fn=seed_device, gather_dst=dst, balance=balance, gather_tensors=not finishing)
         self.last_shards = shards
-        stage, self._finish_stage = getattr(self, "_finish_stage", None), None
-        if stage is not None:                 # RDKit's gate: this rank's shard is finished here, the Mols travel as objects
-            done = mcg_dist.gather_objects(self._collect_finish(stage), shards, group, dst)
+        self._finish_stage = None
+        if finishing:                         # RDKit's gate: this rank's shard was finished above, the Mols travel as objects
+            done = mcg_dist.gather_objects(finished[0], shards, group, dst)
             self.last_host_assembly_ms = 0.0
             kept = [m for m in done if m is not None]
             self.last_valid_fraction = len(kept) / len(done) if done else 0.0

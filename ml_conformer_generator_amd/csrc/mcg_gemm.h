@@ -293,6 +293,7 @@ __global__ __launch_bounds__(256) void mcg_gemm_bf16_kernel(McgGemmArgs p) {
 // per output element as the kernel above: bit-identical results (tests/test_hip_parity.py).
 constexpr int MCG_LDSG_WAVES = 9, MCG_LDSG_RN = 3, MCG_LDSG_THREADS = MCG_LDSG_WAVES * 64, MCG_LDSG_TILES = MCG_LDSG_WAVES * MCG_LDSG_RN;
 constexpr int MCG_LDSG_MAX_BLOCKS = 28;                 // k-blocks of 32 a workgroup can park: 28 x 2 KB = 56 KB of LDS
+constexpr int MCG_LDSG_S2P = 2;                         // k-blocks of the SECOND K segment one wave parks (b2 <= S2P x WAVES)
 
 __device__ __forceinline__ void mcg_gemm_side_job_n(const McgGemmArgs& p, int block, int threads) {
     const int idx = block * threads + (int)threadIdx.x;
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(MCG_LDSG_THREADS) void mcg_gemm_bf16_lds_kernel(Mcg
     //      bf16 rounding - exactly the A-loader of mcg_gemm_bf16_kernel).  Its loads are ISSUED here, in front of the first
     //      barrier, and consumed behind the K loop over segment 1 (their latency hides under it)
     constexpr int NS = GATHER >= 2 ? GATHER : 1;
-    constexpr int S2P = SEG2 ? 2 : 0;                      // k-blocks of segment 2 per wave (b2 <= 14 over 9 waves)
+    constexpr int S2P = SEG2 ? MCG_LDSG_S2P : 0;           // k-blocks of segment 2 per wave (b2 <= 18 = S2P x 9 waves: mcg_gemm_bf16_lds_ok)
     f32x4 s2[SEG2 ? 2 : 1][4][NS];
     const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A2 ? p.A2 : p.A1), 0, 0xffffffff, 0x00020000);
     int srow[4][NS];
@@ -1102,8 +1103,11 @@ static inline hipError_t mcg_gemm16_launch(McgGemmArgs a, int rn, hipStream_t s,
 constexpr int MCG_LDSG_MIN_ROWBLOCKS = 80;
 
 static inline bool mcg_gemm_bf16_lds_ok(const McgGemmArgs& a) {
-    const int blocks = (a.K1 > 0 ? mcg_kblocks16(a.K1) : 0) + (a.K2 > 0 ? mcg_kblocks16(a.K2) : 0);
-    return blocks >= 1 && blocks <= MCG_LDSG_MAX_BLOCKS && a.n_tiles % MCG_LDSG_RN == 0;
+    const int b2 = a.K2 > 0 ? mcg_kblocks16(a.K2) : 0;
+    const int blocks = (a.K1 > 0 ? mcg_kblocks16(a.K1) : 0) + b2;
+    // (the second segment is parked by 9 waves x S2P blocks: a longer one would leave fragments unparked and the K loop
+    //  would read uninitialised LDS - no EGNN shape comes near (b2 = 14), but "forced on" must stay within what is parked)
+    return blocks >= 1 && blocks <= MCG_LDSG_MAX_BLOCKS && b2 <= MCG_LDSG_S2P * MCG_LDSG_WAVES && a.n_tiles % MCG_LDSG_RN == 0;
 }
 
 static inline hipError_t mcg_gemm_bf16_lds_launch(const McgGemmArgs& a, hipStream_t s) {

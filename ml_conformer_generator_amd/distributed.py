@@ -210,7 +210,7 @@ def gather_objects(local: List, shards: List[torch.Tensor], group=None, dst: Opt
 def sharded_generate(n_samples: int, draw_sizes: Callable[[], torch.Tensor],
                      run_shard: Callable[[torch.Tensor, torch.Tensor], Dict[str, torch.Tensor]], group=None,
                      seed: Optional[int] = None, seed_fn: Optional[Callable[[int], None]] = None,
-                     gather_dst: Optional[int] = None, balance: str = "cost"
+                     gather_dst: Optional[int] = None, balance: str = "cost", gather_tensors: bool = True
                      ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], List[torch.Tensor]]:
     """The sharded generation step every multi-GPU entry point goes through
     (`MLConformerGenerator.generate_conformers_sharded`, `bench.py --gpus N`):
@@ -256,4 +256,6 @@ def sharded_generate(n_samples: int, draw_sizes: Callable[[], torch.Tensor],
         if failure is not None:
             raise ShardError(f"{msg}; this rank ({rank}): {type(failure).__name__}: {failure}") from failure
         raise ShardError(msg + f"; this rank ({rank}) finished its shard")
+    if not gather_tensors:
+        return sizes, local, shards
     return sizes, gather_results(local, n_samples, group, dst=gather_dst, shards=shards), shards

@@ -129,7 +129,7 @@ class OrderStage:
             if len(out) != hi - lo:
                 raise ValueError(f"the order task returned {len(out)} results for {hi - lo} molecules")
             return out
-        return [self.provider(z, c) if len(z) > 0 else (None, None) for z, c in self.items[lo:hi]]
+        return [self.provider(z, c) if len(z) > 0 else None for z, c in self.items[lo:hi]]      # empty = not buildable = dropped
 
     def result(self, g: int):
         lo, hi = self.groups[g]

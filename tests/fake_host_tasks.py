@@ -91,3 +91,32 @@ def introspect_chunk(items):
     heavy = sorted(m for m in sys.modules if m.split(".")[0] in ("torch", "ml_conformer_generator_amd"))
     return [{"pid": os.getpid(), "ppid": os.getppid(), "argv0": sys.argv[0], "heavy": heavy,
              "omp": os.environ.get("OMP_NUM_THREADS")} for _ in items]
+
+
+def hang_on_7(items):
+    """A task that never returns for one of its molecules (RDKit is C++: a pathological MMFF does not come back)."""
+    if 7 in items:
+        while True:
+            time.sleep(3600)
+    return [i + 100 for i in items]
+
+
+class TaskLocalError(Exception):
+    """Defined in a file the worker loads BY PATH (module `_mcg_host_task_<n>`): the parent cannot import it."""
+
+
+def raise_task_local(items):
+    raise TaskLocalError("only the worker knows this class")
+
+
+def sys_path_chunk(items):
+    return [list(sys.path) for _ in items]
+
+
+def finish_tag_chunk(items, optimise_geometry):
+    """A finished 'molecule' per item (never dropped): what travels through `distributed.gather_objects`."""
+    return [("mol", len(z), bool(optimise_geometry)) for z, _, _ in items]
+
+
+def finish_raises_chunk(items, optimise_geometry):
+    raise RuntimeError("finisher fault injected")

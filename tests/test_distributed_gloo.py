@@ -255,6 +255,82 @@ def test_failing_shard_raises_on_every_rank_world2_gloo():
     assert res == [(0, ("ShardError", True, True), True), (1, ("ShardError", True, True), True)]
 
 
+def _finishing_shard(gen):
+    """`_generate_shard` with the device work stubbed but the FINISH stage real: shards with molecules build a
+    `FinishStage` over the generator's finisher the way the product does; an EMPTY shard goes through the product's own
+    `_generate_shard` (its n_samples == 0 path needs no GPU)."""
+    from ml_conformer_generator_amd import host_pool as HP
+    from ml_conformer_generator_amd import rdkit_finish as RF
+    from ml_conformer_generator_amd.conformer_generator import MLConformerGenerator
+    from ml_conformer_generator_amd.handoff import molecules_from_tensors
+    stub = _stub_shard([])
+
+    def run(ref_context, ref_n_atoms, variance, sizes, n_samples, *rest):
+        if n_samples == 0:
+            return MLConformerGenerator._generate_shard(gen, ref_context, ref_n_atoms, variance, sizes, n_samples, *rest)
+        res = stub(ref_context, ref_n_atoms, variance, sizes, n_samples, *rest)
+        fin = RF.FinishStage(gen.finisher, True, HP.SerialExecutor())
+        fin.add(molecules_from_tensors(res["x"], res["elements"], res["bond"], res["n_nodes"], res["valid"]))
+        gen._finish_stage = fin
+        return res
+    return run
+
+
+def _finisher_worker(rank, world, port, q):
+    import time
+    from ml_conformer_generator_amd import host_pool as HP
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fake = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_host_tasks.py")
+    torch.manual_seed(1000 + 17 * rank)
+    gen = _shell_generator()
+    gen.n_host_workers = 0
+    gen.finisher = HP.TaskRef(fake, "finish_tag_chunk")
+    gen._generate_shard = _finishing_shard(gen)
+    ctx = torch.tensor([50.0, 100.0, 130.0])
+    res = []
+    # (a) ONE sample on two ranks: rank 1's shard is empty - it must still take part in the object gather (advisor, round 5:
+    #     it took the tensor path and the other rank sat in all_gather_object until the backend timed out)
+    t0 = time.time()
+    mols = gen.generate_conformers_sharded(reference_context=ctx, n_atoms=27, variance=0, n_samples=1)
+    res.append(mols == [("mol", 27, True)] and time.time() - t0 < 30.0)
+    # (b) a ragged batch, gather to rank 0 only: sample order on rank 0, the own shard elsewhere
+    mols = gen.generate_conformers_sharded(reference_context=ctx, n_atoms=27, variance=12, n_samples=9, gather="rank0")
+    torch.manual_seed(1000)
+    torch.randint(27, 28, (1,))                    # (a)'s size draw on rank 0 ...
+    torch.randint(0, 2 ** 31 - 1, (1,))            # ... and its base noise seed (`draw_base_seed`)
+    expect = torch.randint(15, 40, (9,))
+    mine = expect if rank == 0 else expect[assign_shards(expect, world)[rank]]
+    res.append(mols == [("mol", int(v), True) for v in mine.tolist()])
+    # (c) the finish FAILS on rank 1 only: every rank raises ShardError within seconds (it ran behind the status exchange
+    #     before: rank 1 raised alone and rank 0 waited in the object gather)
+    if rank == 1:
+        gen.finisher = HP.TaskRef(fake, "finish_raises_chunk")
+    t0 = time.time()
+    try:
+        gen.generate_conformers_sharded(reference_context=ctx, n_atoms=27, variance=2, n_samples=6)
+        res.append("returned")
+    except ShardError as e:
+        res.append(("rank(s) [1]" in str(e)) and (("finisher fault injected" in str(e)) == (rank == 1)) and time.time() - t0 < 30.0)
+    q.put((rank, res))
+    dist.barrier()                                  # nobody is parked in a half-done collective
+    dist.destroy_process_group()
+
+
+def test_finisher_path_world2_gloo_empty_shard_and_failing_finish():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_finisher_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, [True, True, True]), (1, [True, True, True])]
+
+
 def test_sharded_path_without_a_process_group_is_the_plain_call():
     torch.manual_seed(5)
     expect = torch.randint(25, 30, (6,))

@@ -484,3 +484,87 @@ def test_rdkit_finish_follows_the_reference_call_sequence():
     assert chem.log[3:] == [("AddBond", 1, 0, "D"), ("AddBond", 2, 1, "S"), ("AddBond", 3, 0, "A"), ("AddBond", 3, 2, "T")]
     chem2 = _RecordingChem()
     assert rdkit_finish.mol_without_bonds(rec, Chem=chem2) == {"xyz": rec.to_xyz_block()} and len(chem2.log) == 1
+
+
+# ------------------------------------------------------------------------------------------------ CPU / NUMA placement (round 6)
+def _fake_sysfs(tmp_path, gpu_nodes, cpulists, cpu_nodes=2):
+    """A sysfs tree like an 8-GPU two-socket box: KFD topology nodes 0..cpu_nodes-1 are CPUs (simd_count 0), then one per GPU
+    with its render minor; /sys/class/drm/renderD<minor>/device/numa_node; /sys/devices/system/node/node<k>/cpulist."""
+    root = str(tmp_path)
+    k = 0
+    for _ in range(cpu_nodes):
+        d = os.path.join(root, "sys/class/kfd/kfd/topology/nodes", str(k)); os.makedirs(d)
+        open(os.path.join(d, "properties"), "w").write("cpu_cores_count 64\nsimd_count 0\ndrm_render_minor -1\n")
+        k += 1
+    for g, node in enumerate(gpu_nodes):
+        d = os.path.join(root, "sys/class/kfd/kfd/topology/nodes", str(k)); os.makedirs(d)
+        open(os.path.join(d, "properties"), "w").write(f"cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor {128 + g}\n")
+        dd = os.path.join(root, "sys/class/drm", f"renderD{128 + g}", "device"); os.makedirs(dd)
+        open(os.path.join(dd, "numa_node"), "w").write(f"{node}\n")
+        k += 1
+    for n, text in enumerate(cpulists):
+        d = os.path.join(root, "sys/devices/system/node", f"node{n}"); os.makedirs(d)
+        open(os.path.join(d, "cpulist"), "w").write(text + "\n")
+    return root
+
+
+def test_rank_cpus_follow_the_gpus_numa_node_from_sysfs_alone(tmp_path):
+    """Round-5 review, multi-GPU readiness: 8 ranks x (torch threads + host-pool workers) on a two-socket host with no
+    placement.  `affinity.rank_cpus` reads the GPU's NUMA node and that node's cores from sysfs (no HIP call) and divides
+    them between the ranks whose GPUs share the node."""
+    from ml_conformer_generator_amd import affinity as A
+    assert A.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and A.parse_cpulist("") == []
+    root = _fake_sysfs(tmp_path, gpu_nodes=[0, 0, 0, 0, 1, 1, 1, 1], cpulists=["0-63,128-191", "64-127,192-255"])
+    env = {}
+    allowed = list(range(256))
+    assert A.gpu_render_minors(root) == list(range(128, 136))
+    assert [A.gpu_numa_node(g, root, env) for g in range(8)] == [0, 0, 0, 0, 1, 1, 1, 1]
+    sets = [A.rank_cpus(r, 8, None, root, allowed, env) for r in range(8)]
+    assert all(len(s) == 32 for s in sets)                                   # 128 cores per node / 4 ranks per node
+    assert sorted(c for s in sets for c in s) == allowed                      # a partition: no core shared, none idle
+    node0 = set(A.numa_cpus(0, root))
+    assert all(set(s) <= node0 for s in sets[:4]) and all(not (set(s) & node0) for s in sets[4:])
+    assert sets[0] == list(range(0, 32)) and sets[3] == list(range(160, 192)) and sets[4] == list(range(64, 96))
+    # fewer ranks than GPUs: a lone rank on GPU 0 gets its whole node; 2 ranks on GPUs 0, 1 share node 0
+    assert A.rank_cpus(0, 1, None, root, allowed, env) == sorted(node0)
+    assert [len(A.rank_cpus(r, 2, None, root, allowed, env)) for r in range(2)] == [64, 64]
+    # the cgroup allows fewer cores: only those are handed out
+    assert A.rank_cpus(5, 8, None, root, list(range(64, 72)), env) == [66, 67]
+    # *_VISIBLE_DEVICES re-maps device indices: rank 0 of 1 on physical GPU 6 sits on node 1
+    assert A.gpu_numa_node(0, root, {"HIP_VISIBLE_DEVICES": "6"}) == 1
+    assert A.visible_gpu_minors(root, {"ROCR_VISIBLE_DEVICES": "4,5,6,7", "HIP_VISIBLE_DEVICES": "1"}) == [133]
+    assert set(A.rank_cpus(0, 1, None, root, allowed, {"HIP_VISIBLE_DEVICES": "6"})) == set(allowed) - node0
+    # an explicit device for this rank (rank 1 drives GPU 5)
+    assert set(A.rank_cpus(1, 2, 5, root, allowed, env)) <= set(allowed) - node0
+    # unknown topology (numa_node -1, or no sysfs at all): an even split of the allowed cores by local rank - never an error
+    root2 = _fake_sysfs(tmp_path / "b", gpu_nodes=[-1, -1], cpulists=["0-15"], cpu_nodes=1)
+    assert A.rank_cpus(1, 2, None, root2, list(range(16)), env) == list(range(8, 16))
+    assert A.rank_cpus(0, 4, None, str(tmp_path / "nowhere"), list(range(8)), env) == [0, 1]
+    assert A.rank_cpus(3, 4, None, str(tmp_path / "nowhere"), [5], env) == [5]
+
+
+def test_pin_moves_every_thread_and_children_inherit_it():
+    """`sched_setaffinity(0, ...)` moves the calling thread only; `affinity.pin` walks /proc/self/task.  Run in a child process
+    (it narrows its own mask and must not touch the test runner's)."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import os, sys, threading, subprocess, time
+        sys.path.insert(0, %r)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("aff", %r)
+        A = importlib.util.module_from_spec(spec); spec.loader.exec_module(A)
+        allowed = sorted(os.sched_getaffinity(0))
+        stop = threading.Event(); seen = {}
+        def bg():
+            stop.wait(); seen["bg"] = sorted(os.sched_getaffinity(0))
+        t = threading.Thread(target=bg); t.start()
+        want = allowed[:2] if len(allowed) >= 2 else allowed
+        got = A.pin(want)
+        stop.set(); t.join()
+        child = subprocess.run([sys.executable, "-c", "import os; print(sorted(os.sched_getaffinity(0)))"], capture_output=True, text=True)
+        print(got == want, seen["bg"] == want, child.stdout.strip() == str(want), A.pin([]) == [])
+    """) % (REPO, os.path.join(REPO, "ml_conformer_generator_amd", "affinity.py"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert out.stdout.split() == ["True", "True", "True", "True"], out.stdout + out.stderr

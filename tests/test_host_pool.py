@@ -232,3 +232,99 @@ def test_pipeline_overlaps_order_and_finish_of_different_groups(pool):
     o_p, r_p, t_p = min((run(pool, "order_chunk") for _ in range(3)), key=lambda t: t[2])
     assert o_s == o_p and r_s == r_p
     assert t_s / t_p >= 5.0, f"serial {t_s * 1e3:.0f} ms, pooled pipeline {t_p * 1e3:.0f} ms"
+
+
+# ------------------------------------------------------------------------------------------------ hardening (round 6)
+def test_a_stuck_worker_is_killed_replaced_and_its_molecules_dropped_with_a_warning():
+    """Round-5 review: dead workers were replaced, stuck ones were not - a worker that never returns from RDKit parked
+    `generate_conformers` forever.  With a deadline the serving thread kills THAT child by handle, replaces it, and the
+    chunk's molecules come back as None (= dropped, the reference's "any failure => invalid") - no exception."""
+    import warnings
+    with HP.HostPool(2, task_timeout_s=0.5) as p:
+        before = set(p.worker_pids())
+        t0 = time.perf_counter()
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter("always")
+            futs = [p.submit(ref("hang_on_7"), [lo, lo + 1]) for lo in range(0, 12, 2)]
+            out = [f.result(timeout=30) for f in futs]
+        took = time.perf_counter() - t0
+        assert out == [[100, 101], [102, 103], [104, 105], [None, None], [108, 109], [110, 111]]
+        assert took < 10.0, f"{took:.1f} s: the deadline was not enforced"
+        msgs = [str(w.message) for w in seen if issubclass(w.category, RuntimeWarning)]
+        assert len(msgs) == 1 and "hang_on_7" in msgs[0] and "0.5 s" in msgs[0] and "dropped" in msgs[0]
+        assert p.tasks_timed_out == 1 and p.workers_replaced == 1
+        after = set(p.worker_pids())
+        assert len(after) == 2 and after != before
+        (gone,) = before - after
+        time.sleep(0.1)
+        with pytest.raises(OSError):                  # the stuck child itself was ended (reaped: no zombie either)
+            os.kill(gone, 0)
+        assert p.submit(ref("hang_on_7"), [1, 2]).result(timeout=30) == [101, 102]       # the replacement works
+        # per-task override: no deadline at all for this one, a long one for that
+        assert p.submit(ref("sleep_chunk"), [3], (0.8,), timeout=None).result(timeout=30)[0][0] == 3
+        assert p.submit(ref("sleep_chunk"), [4], (0.8,), timeout=5.0).result(timeout=30)[0][0] == 4
+        assert p.tasks_timed_out == 1
+    with pytest.raises(ValueError):
+        HP.HostPool(2, task_timeout_s=0.0)
+    # the shared pool is keyed by (workers, deadline); the serial executor takes the argument and ignores it
+    assert HP.shared_pool(3, 5.0) is HP.shared_pool(3, 5.0) and HP.shared_pool(3, 5.0) is not HP.shared_pool(3, None)
+    assert HP.shared_pool(3).task_timeout_s == HP.DEFAULT_TASK_TIMEOUT_S == 60.0
+    assert HP.SerialExecutor().submit(ref("square_chunk"), [2], (), timeout=0.001).result() == [4]
+
+
+def test_an_exception_class_only_the_worker_can_import_still_resolves_the_future(pool):
+    """Advisor (round 5): a reply that does not unpickle in the parent killed the serving thread and left `.result()` waiting
+    forever.  The worker now sends such exceptions as RuntimeError naming the type; the pool survives."""
+    f = pool.submit(ref("raise_task_local"), [1, 2])
+    with pytest.raises(RuntimeError, match="TaskLocalError: only the worker knows this class") as ei:
+        f.result(timeout=30)
+    assert "raise_task_local" in ei.value.worker_traceback
+    assert HP.map_ordered(pool, ref("square_chunk"), [2, 3]) == [4, None]
+    assert all(t.is_alive() for t in pool._threads)
+
+
+def test_workers_do_not_have_the_package_directory_on_sys_path(pool):
+    """Advisor (round 5): run by file path, a worker had the package's own directory as sys.path[0] - `config.py`,
+    `distributed.py`, `schedule.py` ... shadowed top-level modules of the same name for everything a task imports."""
+    pkg = os.path.dirname(os.path.abspath(HP.__file__))
+    for path in pool.submit(ref("sys_path_chunk"), [0, 1]).result(timeout=30):
+        assert all(os.path.abspath(p or ".") != pkg for p in path), path
+
+
+def test_prestart_spawns_the_workers_in_the_background_and_submit_waits_for_it():
+    """Round-5 review: the pool started at the first submit - AFTER the sampler - so the first call paid the workers'
+    start-up serially.  `prestart()` returns at once; the generator calls it before it launches the sampler."""
+    p = HP.HostPool(4)
+    try:
+        t0 = time.perf_counter()
+        p.prestart([ref("square_chunk")])              # + the task file: the workers import it (numpy) as they come up
+        p.prestart()                                   # idempotent while the start is in progress
+        assert time.perf_counter() - t0 < 0.05 and HP.SerialExecutor().prestart() is None
+        assert p.submit(ref("square_chunk"), [5]).result(timeout=60) == [25]       # an early submit waits for the start
+        assert len(p.worker_pids()) == 4 and p.last_start_ms is not None
+        time.sleep(0.05)
+        t0 = time.perf_counter()
+        p.prestart()                                   # already running: nothing to do
+        assert time.perf_counter() - t0 < 0.01 and len(p.worker_pids()) == 4
+        # what is left on the critical path once the workers are up and hold the task file: one round trip per worker
+        time.sleep(1.0)
+        t0 = time.perf_counter()
+        got = [f.result(timeout=60) for f in [p.submit(ref("sleep_chunk"), [k], (0.005,)) for k in range(4)]]
+        assert (time.perf_counter() - t0) * 1e3 < 20.0 and len({pid for ((_, pid),) in got}) == 4
+    finally:
+        p.close()
+
+
+def test_an_empty_molecule_is_dropped_not_built_without_connectivity():
+    """Advisor (round 5): `order_chunk` returned (None, None) for an empty molecule - "built, no connectivity" - and the stage
+    then raised the every-molecule-or-none ValueError once the others supplied connectivities."""
+    from ml_conformer_generator_amd import _rdkit_tasks as T
+    assert T.order_chunk([([], np.zeros((0, 3)))], {}) == [None]
+    from ml_conformer_generator_amd import rdkit_order as RO
+    x, h, n = _batch(B=8)
+    n[3] = 0
+    import sys
+    sys.path.insert(0, os.path.dirname(FAKE))
+    import fake_host_tasks as F
+    o, c, b = RO.batch_order_and_connectivity(lambda z, cc: F.order_chunk_no_sleep([(z, cc)])[0], x, h, n)
+    assert b[3] is False and sum(b) == 6 and c[3].shape == (0, 0)          # molecule 5 is the Br one, molecule 3 the empty one
