@@ -56,11 +56,8 @@ int mcg_egnn_set_precision(mcg_egnn* m, int mode);
  *   MCG_OPT_GEMM_RN     [0]  wave tile width (column tiles) of the 32-row node GEMM kernel: 0 = cost model, 1..3
  *   MCG_OPT_GEMM_X6_RN  [0]  same for the split-operand GEMM kernel
  *   MCG_OPT_GEMM_BF16_LDS [0] bf16 mode: 0 = the LDS-staged 9-wave node GEMM from 80 row blocks (2 560 atoms) on, 1 = never (32-row kernel),
- *                            2 = whenever its shape limits allow (results are bit-identical either way)
- *   MCG_OPT_EDGE_BF16_PAIR [0] bf16 mode, 64-row plans: 0 = eight-wave edge workgroups over TWO 64-row units each (every W2 fragment
- *                            feeds eight MFMAs: half the weight stream per CU) from 1 024 units on, 1 = never (four-wave workgroups,
- *                            one unit each), 2 = always (results are bit-identical either way) */
-enum { MCG_OPT_X6_GEMM = 1, MCG_OPT_GEMM_RN = 2, MCG_OPT_GEMM_X6_RN = 3, MCG_OPT_GEMM_BF16_LDS = 4, MCG_OPT_EDGE_BF16_PAIR = 5 };
+ *                            2 = whenever its shape limits allow (results are bit-identical either way) */
+enum { MCG_OPT_X6_GEMM = 1, MCG_OPT_GEMM_RN = 2, MCG_OPT_GEMM_X6_RN = 3, MCG_OPT_GEMM_BF16_LDS = 4 };
 /* Both setters may be called at any time between denoiser calls: a plan that has already captured its launches as a HIP
  * graph re-captures on its next call (the graph is keyed by the model's option epoch). */
 int mcg_egnn_set_option(mcg_egnn* m, int option, int value);

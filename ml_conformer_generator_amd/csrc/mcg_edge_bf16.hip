@@ -240,65 +240,38 @@ __global__ __launch_bounds__(256, 2) void k_edge_lds_bf16(EdgeArgs p) {
 // 7x and every B fragment 4x from registers (11 fragment reads per 28 MFMAs).  The A operand (layer-1 finish
 // + SiLU, rounded to bf16) of row tile w is produced once by wave w and shared through LDS; the gate /
 // coordinate-head dot product is completed across the waves through LDS in fixed order.
-constexpr int W64_A_FLOATS = 2 * 4 * 64 * 4;          // A tile ring of ONE 64-row unit: [2][4 row tiles][64 lanes] x 16 B (per operand part)
+constexpr int W64_A_FLOATS = 2 * 4 * 64 * 4;          // A tile ring: [2][4 row tiles][64 lanes] x 16 B (per operand part)
 constexpr int W64_KP = 32 * ((H + 31) / 32);            // 448: k range of the padded 32-k blocks
-// U = 64-row units per workgroup (1: four waves, 2: eight waves over 128 rows - below)
-template <int SPLIT, int U> constexpr int w64_lds_floats() { return 2 * HP + 2 * W64_KP + SPLIT * U * W64_A_FLOATS + 8 * 64 * U + 64 * U * 4 + 64 * U; }   // 18 / 34 / 30 KiB
+template <int SPLIT> constexpr int w64_lds_floats() { return 2 * HP + 2 * W64_KP + SPLIT * W64_A_FLOATS + 4 * 64 + 64 * 4; }   // 17 / 33 KiB
 // SPLIT = 1: bf16 operands (one product).  SPLIT = 3: "f32x6" - every fp32 operand is carried as the exact sum of
 // three bf16 parts (a = a1 + a2 + a3, |a2| <= 2^-8 |a|, |a3| <= 2^-16 |a|; same for the weights, split on the
 // host) and the six partial products of weight >= 2^-16 (a1 b1, a2 b1, a3 b1, a1 b2, a2 b2, a1 b3) are accumulated
 // in fp32: the dropped terms are <= 2^-23 relative, i.e. the contraction is fp32-accurate, on a matrix pipe that is
 // 16x faster per k than v_mfma_f32_16x16x4_f32 (6/16 of the exact kernel's matrix time).  The weight parts are
 // streamed part-major per 32-k block (stage = kb*3 + part); part p meets the activation parts 0 .. 2-p.
-//
-// U = 2 (round 6, bf16 mode, large plans): ONE workgroup of EIGHT waves owns TWO consecutive 64-row units = 8 row tiles, and its
-// waves split the 27 column tiles EIGHT ways (4,4,4,3,3,3,3,3: wave w takes tiles w, w + 8, w + 16, w + 24).  A wave keeps an
-// 8 x 4 grid of accumulators (128 VGPRs, 112 before), so every W2 fragment it fetches from L2 now feeds EIGHT MFMAs instead of
-// four: per CU and k-block 27 weight-fragment loads instead of 56 (two 4-wave workgroups each streaming all of W2) - the weight
-// stream that was 7 of the 11 vector-memory instructions per wave and block (profiles/round5_probes.txt: 38 us of each CU's
-// memory pipeline per launch, 1.2 GB of L2 reads) is HALVED, with the fragments still going straight into registers: no LDS
-// ring for W2, no extra LDS reads for it, no extra rendezvous (the alternative - two 4-wave halves that keep their 7 column
-// tiles and share W2 through a 3-stage LDS ring - needs 81 KiB of LDS, 7 more ds_read_b128 per wave and block and DMA
-// landing times in the barrier protocol for the same halving).  The A operand of row tile w is still generated once, by wave
-// w, and shared through the LDS ring (8 fragment reads per wave and block instead of 4); waves w and w + 4 share a SIMD and
-// carry 4 + 3 column tiles = the 7 of today's two waves per SIMD: same matrix-pipe load per SIMD, 2 waves per SIMD kept (one
-// 8-wave workgroup per CU, <= 256 VGPRs).
-// So that the two geometries can be compared BIT FOR BIT, the gate / coordinate-head dot product is summed in an order both
-// can produce: per column-tile residue class mod 8 (a chain of fmas over the tiles t, t + 8, t + 16, t + 24, then the 16-lane
-// butterfly), the eight class sums added in class order.  With U = 1 a wave owns two classes (w and w + 4), with U = 2 one.
-template <bool EQUIV, int SPLIT, bool BLK = false, int U = 1>
-__global__ __launch_bounds__(256 * U, 2) void k_edge_bf16_w64(EdgeArgs p) {
+template <bool EQUIV, int SPLIT, bool BLK = false>
+__global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
     static_assert(!BLK || SPLIT == 1, "the blocked layer-1 input layout is the bf16 mode's");
-    static_assert(U == 1 || SPLIT == 1, "eight-wave workgroups are the bf16 mode's");
-    constexpr int WAVES = 4 * U, RT = 4 * U, ROWS = 64 * U, THREADS = 256 * U;
-    constexpr int NSW = (NT + WAVES - 1) / WAVES;          // column tiles per wave: 7 (tiles w + 4 i) or 4 (w + 8 i)
-    constexpr int CH = 8 / WAVES;                           // residue classes mod 8 a wave's column tiles fall into
-    __shared__ __attribute__((aligned(16))) float lds[w64_lds_floats<SPLIT, U>()];
+    __shared__ __attribute__((aligned(16))) float lds[w64_lds_floats<SPLIT>()];
     float* const par = lds;                                              // b2 | wv
     float* const wdl = par + 2 * HP;                                     // wd | wd0 (layer-1 distance weights): read at
                                                                          // A-generation time instead of being held in
                                                                          // 16 VGPRs across a whole k-block
-    bf16x8* const a_lds = reinterpret_cast<bf16x8*>(wdl + 2 * W64_KP);   // [2][SPLIT][RT][64]
-    float* const xchg = wdl + 2 * W64_KP + SPLIT * U * W64_A_FLOATS;     // [8 classes][ROWS rows]
-    float* const ri = xchg + 8 * ROWS;                                   // [ROWS rows][4]: seg, ux, uy, uz
-    int* const sgl = reinterpret_cast<int*>(ri + 4 * ROWS);              // [ROWS rows]: seg again, contiguous (one 16-byte read = 4 rows)
-    for (int i = threadIdx.x; i < HP; i += THREADS) { par[i] = p.b2[i]; par[HP + i] = p.wv[i]; }
-    for (int i = threadIdx.x; i < W64_KP; i += THREADS) { wdl[i] = p.wd[i]; wdl[W64_KP + i] = p.wd0[i]; }
+    bf16x8* const a_lds = reinterpret_cast<bf16x8*>(wdl + 2 * W64_KP);   // [2][SPLIT][4][64]
+    float* const xchg = wdl + 2 * W64_KP + SPLIT * W64_A_FLOATS;         // [4 waves][64 rows]
+    float* const ri = xchg + 4 * 64;                                     // [64 rows][4]: seg, ux, uy, uz
+    for (int i = threadIdx.x; i < HP; i += 256) { par[i] = p.b2[i]; par[HP + i] = p.wv[i]; }
+    for (int i = threadIdx.x; i < W64_KP; i += 256) { wdl[i] = p.wd[i]; wdl[W64_KP + i] = p.wd0[i]; }
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
-    const int wg = mcg_xcd_remap(blockIdx.x, gridDim.x);                 // U consecutive 64-row units ("waves" of the MT = 4 plan)
-#ifndef MCG_W128_DEPHASE
-#define MCG_W128_DEPHASE 1
-#endif
-    // U = 2: accumulator row mt of the upper four waves holds PHYSICAL row tile (mt + 4) % 8 (see stage_mfma_cols)
-    const int prot = (U == 2 && MCG_W128_DEPHASE) ? (wid & 4) : 0;
+    const int unit = mcg_xcd_remap(blockIdx.x, gridDim.x);               // 64-row unit == "wave" of the MT = 4 plan
 
-    // rows of MY row tile (tile wid of the workgroup): A-operand generation + row facts for everybody's epilogue
+    // rows of MY row tile (tile wid of the unit): A-operand generation + row facts for everybody's epilogue
     int vi = 0, vj = 0, sg = -1;
     float d2, d02, ux = 0.f, uy = 0.f, uz = 0.f;
     {
-        const int tile = wg * RT + wid;
+        const int tile = unit * 4 + wid;
         const int r = tile * 16 + c;
         if (tile < p.n_mtiles) {
             const int2 ij = p.row_ij[r];
@@ -319,7 +292,6 @@ __global__ __launch_bounds__(256 * U, 2) void k_edge_bf16_w64(EdgeArgs p) {
         if (g == 0) {
             float* dst = ri + (16 * wid + c) * 4;
             dst[0] = __int_as_float(sg); dst[1] = ux; dst[2] = uy; dst[3] = uz;
-            sgl[16 * wid + c] = sg;
         }
     }
     // Operand addresses are (buffer descriptor in SGPRs) + (one 32-bit lane offset) + (scalar block offset): as
@@ -342,33 +314,32 @@ __global__ __launch_bounds__(256 * U, 2) void k_edge_bf16_w64(EdgeArgs p) {
     const float* wdp = wdl + 8 * g;
     const float* w0p = wdl + W64_KP + 8 * g;
 
-    f32x4 acc[RT][NSW];
+    f32x4 acc[4][NS_T];
 #pragma unroll
-    for (int mt = 0; mt < RT; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int i = 0; i < NSW; ++i) acc[mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NS_T; ++i) acc[mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // B fragments: straight from global/L2 into a 2-deep REGISTER ring (each wave streams only the column
+    // B fragments: straight from global/L2 into a 2-deep REGISTER ring (each wave streams only the 7 column
     // tiles it owns; per workgroup that is the same 363 KB of W2 an LDS stage would move, without the stage's
     // one-block latency budget: an LDS-DMA issued at the top of a 450-cycle bf16 block has not landed when the
-    // next block starts, which is what bounds k_edge_lds_bf16).  One ring stage = the wave's NSW fragments of one
-    // (k-block, weight part): tiles wid, wid + WAVES, ... (the last one clamped to 26 where it runs past, result unused).
+    // next block starts, which is what bounds k_edge_lds_bf16).  One ring stage = the wave's 7 fragments of one
+    // (k-block, weight part): tiles wid, wid+4, .., wid+24 (the last one clamped to 26 for wave 3, result unused).
     constexpr int NSTAGE = KB16 * SPLIT;
     constexpr int STAGE_BYTES = NT * 64 * 16;
-    constexpr int SLOT_BYTES = WAVES * 64 * 16;                 // from one of a wave's column tiles to its next
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Bp), 0, NSTAGE * STAGE_BYTES, 0x00020000);
     const unsigned ov = (unsigned)(wid * 64 + lane) * 16u;
-    const unsigned ov6 = (unsigned)((wid + WAVES * (NSW - 1) < NT ? wid + WAVES * (NSW - 1) : NT - 1) * 64 + lane) * 16u;
-    bf16x8 Bq[2][NSW];
+    const unsigned ov6 = (unsigned)((wid + 24 < NT ? wid + 24 : NT - 1) * 64 + lane) * 16u;
+    bf16x8 Bq[2][NS_T];
     auto ld16 = [](const __amdgpu_buffer_rsrc_t& r, unsigned voff, int soff) {
         return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0);
     };
-    auto load_b = [&](bf16x8 (&dst)[NSW], int stage) {
+    auto load_b = [&](bf16x8 (&dst)[NS_T], int stage) {
         stage = stage < NSTAGE ? stage : NSTAGE - 1;
         const int base = stage * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < NSW - 1; ++i) dst[i] = __builtin_bit_cast(bf16x8, ld16(rs_b, ov, base + i * SLOT_BYTES));
-        dst[NSW - 1] = __builtin_bit_cast(bf16x8, ld16(rs_b, ov6, base));
+        for (int i = 0; i < NS_T - 1; ++i) dst[i] = __builtin_bit_cast(bf16x8, ld16(rs_b, ov, base + i * 4 * 64 * 16));
+        dst[NS_T - 1] = __builtin_bit_cast(bf16x8, ld16(rs_b, ov6, base));
     };
     auto load_a = [&](int kb, f32x4 (&v)[4]) {
         kb = kb < KB16 ? kb : KB16 - 1;
@@ -389,7 +360,7 @@ __global__ __launch_bounds__(256 * U, 2) void k_edge_bf16_w64(EdgeArgs p) {
 #pragma unroll
         for (int q = 0; q < SPLIT; ++q) {
             const bf16x8 part = mcg_pack_bf16(lo, hi);
-            a_lds[((half * SPLIT + q) * RT + wid) * 64 + lane] = part;
+            a_lds[((half * SPLIT + q) * 4 + wid) * 64 + lane] = part;
             if (q + 1 < SPLIT) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { lo[j] -= (float)part[j]; hi[j] -= (float)part[4 + j]; }   // exact in fp32
@@ -397,97 +368,54 @@ __global__ __launch_bounds__(256 * U, 2) void k_edge_bf16_w64(EdgeArgs p) {
         }
     };
     // MFMAs of one ring stage: weight part `part` of block kb against activation parts 0 .. SPLIT-1-part
-    auto stage_mfma = [&](const bf16x8 (&Bc)[NSW], int half, int part, auto&& mid) {
+    auto stage_mfma = [&](const bf16x8 (&Bc)[NS_T], int half, int part, auto&& mid) {
         // A fragments of row tile mt+1 are fetched from LDS while the MFMAs of row tile mt run (pinned: left
         // alone hipcc hoists all 4 x SPLIT fragment reads to the top of the stage and spills)
         const int nq = SPLIT - part;
         bf16x8 af[2][SPLIT];
 #pragma unroll
         for (int q = 0; q < SPLIT; ++q)
-            if (q < nq) af[0][q] = a_lds[((half * SPLIT + q) * RT + 0) * 64 + lane];
+            if (q < nq) af[0][q] = a_lds[((half * SPLIT + q) * 4 + 0) * 64 + lane];
 #pragma unroll
-        for (int mt = 0; mt < RT; ++mt) {
-            if (mt + 1 < RT) {
+        for (int mt = 0; mt < 4; ++mt) {
+            if (mt + 1 < 4) {
 #pragma unroll
                 for (int q = 0; q < SPLIT; ++q)
-                    if (q < nq) af[(mt + 1) & 1][q] = a_lds[((half * SPLIT + q) * RT + mt + 1) * 64 + lane];
+                    if (q < nq) af[(mt + 1) & 1][q] = a_lds[((half * SPLIT + q) * 4 + mt + 1) * 64 + lane];
             }
 #pragma unroll
             for (int q = 0; q < SPLIT; ++q)
                 if (q < nq) {
 #pragma unroll
-                    for (int i = 0; i < NSW; ++i) acc[mt][i] = mcg_mfma_bf16(af[mt & 1][q], Bc[i], acc[mt][i]);
+                    for (int i = 0; i < NS_T; ++i) acc[mt][i] = mcg_mfma_bf16(af[mt & 1][q], Bc[i], acc[mt][i]);
                 }
             if (SPLIT > 1) __builtin_amdgcn_sched_barrier(0);
             if (mt == 1) mid();        // (bf16: the next block's A operand is generated here, under the second half's MFMAs)
         }
     };
-    // bf16 (SPLIT = 1) walks the stage COLUMN tile by column tile: all RT A fragments are read up front (16 / 32 VGPRs), column
-    // tile i's weight fragment meets them in RT MFMAs and is then dead, so its refill for two stages ahead is issued right
+    // bf16 (SPLIT = 1) walks the stage COLUMN tile by column tile: all four A fragments are read up front (16 VGPRs), column
+    // tile i's weight fragment meets them in four MFMAs and is then dead, so its refill for two stages ahead is issued right
     // behind them - the weight stream is requested progressively through the block instead of in one burst after it.
-    auto stage_mfma_cols = [&](bf16x8 (&Bc)[NSW], int half, int next_stage, auto&& mid) {
+    auto stage_mfma_cols = [&](bf16x8 (&Bc)[NS_T], int half, int next_stage, auto&& mid) {
+        bf16x8 af[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) af[mt] = a_lds[(half * 4 + mt) * 64 + lane];
         const int st = next_stage < NSTAGE ? next_stage : NSTAGE - 1;
         const int base = st * STAGE_BYTES;
-#ifndef MCG_W128_COLMAJOR
-#define MCG_W128_COLMAJOR 0          // (measurement switch: 1 = the eight-wave workgroup walks column tile by column tile like the four-wave one)
-#endif
-        if constexpr (U == 2 && !MCG_W128_COLMAJOR) {
-            // eight row tiles: all A fragments up front would be 32 VGPRs on top of 128 accumulators (the loop then spills into
-            // scratch - vector-memory traffic inside the counted waits).  Row tile by row tile instead: fragment mt + 1 is read
-            // while row tile mt's MFMAs run (8 VGPRs), the next block's A operand is generated behind row tile 3, and a weight
-            // fragment is dead after the LAST row tile's MFMA - its refill for two stages ahead goes out right there.
-#ifndef MCG_W128_AF_DEPTH
-#define MCG_W128_AF_DEPTH 3          // A fragments in flight: the read of row tile mt + DEPTH - 1 is issued in front of row tile mt's MFMAs
-#endif
-            constexpr int AD = MCG_W128_AF_DEPTH;
-            // The two waves of a SIMD (w and w + 4) belong to the SAME workgroup here and pass the same barrier every block: left
-            // alone they run in lock step - both on the matrix pipe, then both in the VALU-heavy A generation - and the two pipes
-            // never overlap (two independent 4-wave workgroups drift apart by themselves).  So the upper four waves walk the row
-            // tiles rotated by four and generate the next block's A operand late (behind their 6th row tile) while the lower four
-            // generate it early (behind their 2nd): one wave of a SIMD is in its VALU phase while the other issues MFMAs.
-            // (no second copy of the loop: the rotation is in the ADDRESSES - accumulator row mt of an upper wave holds physical row
-            //  tile (mt + 4) % 8, `prot` below - so only LDS offsets and the epilogue's row numbers know about it)
-            bf16x8 af[AD];
-#pragma unroll
-            for (int q = 0; q < AD - 1; ++q) af[q] = a_lds[(half * RT + ((q + prot) & (RT - 1))) * 64 + lane];
-#pragma unroll
-            for (int mt = 0; mt < RT; ++mt) {
-                if (mt + AD - 1 < RT) af[(mt + AD - 1) % AD] = a_lds[(half * RT + ((mt + AD - 1 + prot) & (RT - 1))) * 64 + lane];
-#pragma unroll
-                for (int i = 0; i < NSW; ++i) {
-                    acc[mt][i] = mcg_mfma_bf16(af[mt % AD], Bc[i], acc[mt][i]);
-                    if (mt == RT - 1) {
-                        __builtin_amdgcn_sched_barrier(0);
-#ifndef MCG_ABL_NOB
-                        Bc[i] = __builtin_bit_cast(bf16x8, i < NSW - 1 ? ld16(rs_b, ov, base + i * SLOT_BYTES) : ld16(rs_b, ov6, base));
-#endif
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (MCG_W128_DEPHASE) {
-                    if (mt == 1 && prot == 0) mid();
-                    if (mt == 5 && prot != 0) mid();
-                } else if (mt == RT / 2 - 1) mid();
-            }
-        } else {
-        bf16x8 af[RT];
-#pragma unroll
-        for (int mt = 0; mt < RT; ++mt) af[mt] = a_lds[(half * RT + mt) * 64 + lane];
 #ifndef MCG_W64_AGEN_POS
-#define MCG_W64_AGEN_POS (NSW / 2)
+#define MCG_W64_AGEN_POS 3
 #endif
         if (MCG_W64_AGEN_POS < 0) { __builtin_amdgcn_sched_barrier(0); mid(); }      // (measurement switch: generation in front of the block's first MFMA)
 #pragma unroll
-        for (int i = 0; i < NSW; ++i) {
+        for (int i = 0; i < NS_T; ++i) {
 #pragma unroll
-            for (int mt = 0; mt < RT; ++mt) acc[mt][i] = mcg_mfma_bf16(af[mt], Bc[i], acc[mt][i]);
+            for (int mt = 0; mt < 4; ++mt) acc[mt][i] = mcg_mfma_bf16(af[mt], Bc[i], acc[mt][i]);
             __builtin_amdgcn_sched_barrier(0);
 #ifndef MCG_ABL_NOB          // (ablation switch: no weight refills - wrong results, an upper bound for any better weight delivery)
-            Bc[i] = __builtin_bit_cast(bf16x8, i < NSW - 1 ? ld16(rs_b, ov, base + i * SLOT_BYTES) : ld16(rs_b, ov6, base));
+            Bc[i] = __builtin_bit_cast(bf16x8, i < NS_T - 1 ? ld16(rs_b, ov, base + i * 4 * 64 * 16) : ld16(rs_b, ov6, base));
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            if (i == MCG_W64_AGEN_POS) mid();          // (U = 1: position 0 / 1 / 3 / 5 measured: no difference)
-        }
+            if (i == MCG_W64_AGEN_POS) mid();          // (position 0 / 1 / 3 / 5 measured: no difference)
         }
     };
     // one k-block: [barrier] A-operand loads of block kb+1 | per weight part: MFMAs, then the B loads two stages
@@ -568,133 +496,116 @@ __global__ __launch_bounds__(256 * U, 2) void k_edge_bf16_w64(EdgeArgs p) {
 
     // ---- epilogue
     __syncthreads();       // (row facts `ri` were written before the first loop barrier; keeps the last block's reads apart)
-    float part[CH][RT][4];
+    float part[4][4];
 #pragma unroll
-    for (int ch = 0; ch < CH; ++ch)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < RT; ++mt)
+        for (int r = 0; r < 4; ++r) part[mt][r] = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part[ch][mt][r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < NSW; ++i) {
-        const int nt = wid + WAVES * i;
+    for (int i = 0; i < NS_T; ++i) {
+        const int nt = wid + 4 * i;
         if (nt >= NT) continue;
         const float b2 = par[nt * 16 + c], wv = par[HP + nt * 16 + c];
 #pragma unroll
-        for (int mt = 0; mt < RT; ++mt) {
+        for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float m = mcg_silu(acc[mt][i][r] + b2);
                 acc[mt][i][r] = m;
-                part[i % CH][mt][r] = fmaf(wv, m, part[i % CH][mt][r]);      // class (wid + WAVES * (i % CH)) mod 8 of tile nt
+                part[mt][r] = fmaf(wv, m, part[mt][r]);
             }
         }
     }
 #pragma unroll
-    for (int ch = 0; ch < CH; ++ch)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < RT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = mcg_row16_sum(part[ch][mt][r]);
-                if (c == 0) xchg[(wid + WAVES * ch) * ROWS + 16 * ((mt + prot) & (RT - 1)) + 4 * g + r] = v;
-            }
-    __syncthreads();
-    // per 64-row unit: this wave finishes ITS column tiles of both units (U = 2) exactly as a 4-wave workgroup finishes its own
-#pragma unroll
-    for (int u = 0; u < U; ++u) {                 // u: the unit whose rows sit in accumulator rows 4 u .. 4 u + 3 of THIS wave
-        const int up = U == 2 ? (u ^ (prot >> 2)) : u;      // ... which is physical unit `up` of the workgroup
-        const int unit = wg * U + up;
-        if (unit >= p.n_waves) continue;          // (odd unit count: the last workgroup's second half is padding)
-        const int nseg = p.wave_poff[unit + 1] - p.wave_poff[unit];
-        const int pbase = p.wave_poff[unit];
-        __builtin_amdgcn_sched_barrier(0);       // (one unit at a time: hoisted, the second unit's LDS reads cost 48 live registers)
-        float dot[4][4];
-        int rseg[4][4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            // rows 4 g .. 4 g + 3 of row tile mt are contiguous in every class's line: 8 + 1 sixteen-byte reads per row tile
-            const int row0 = 64 * up + 16 * mt + 4 * g;
-            f32x4 acc8 = *reinterpret_cast<const f32x4*>(xchg + row0);
-#pragma unroll
-            for (int k = 1; k < 8; ++k) acc8 += *reinterpret_cast<const f32x4*>(xchg + k * ROWS + row0);   // class order: identical for U = 1 and U = 2
-            const int4 s4 = *reinterpret_cast<const int4*>(sgl + row0);
-            const int sv[4] = {s4.x, s4.y, s4.z, s4.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { dot[mt][r] = acc8[r]; rseg[mt][r] = sv[r]; }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int r = 0; r < 4; ++r) {
+            const float v = mcg_row16_sum(part[mt][r]);
+            if (c == 0) xchg[wid * 64 + 16 * mt + 4 * g + r] = v;
         }
-        if (EQUIV) {
-            if (wid != 4 * up) continue;           // one wave per unit does the (tiny) coordinate sums
-            for (int s = 0; s < nseg; ++s) {
-                float sx = 0.f, sy = 0.f, sz = 0.f;
+    __syncthreads();
+    const int nseg = p.wave_poff[unit + 1] - p.wave_poff[unit];
+    const int pbase = p.wave_poff[unit];
+    float dot[4][4];
+    int rseg[4][4];
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (rseg[mt][r] == s) {
-                            const float* q = ri + (64 * up + 16 * mt + 4 * g + r) * 4;
-                            sx += q[1] * dot[mt][r]; sy += q[2] * dot[mt][r]; sz += q[3] * dot[mt][r];
-                        }
-                // each row is held by the 16 lanes of one lane group: divide the 16 identical copies out by summing
-                // over lane groups only (lanes with c == 0 carry the value)
-                sx = mcg_group4_sum(sx); sy = mcg_group4_sum(sy); sz = mcg_group4_sum(sz);
-                if (lane == 0) {
-                    float* dst = p.P + (size_t)(pbase + s) * 4;
-                    dst[0] = sx; dst[1] = sy; dst[2] = sz; dst[3] = 0.f;
-                }
-            }
-        } else {
-            float sel[4][4];
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + 4 * g + r;
+            dot[mt][r] = ((xchg[row] + xchg[64 + row]) + xchg[128 + row]) + xchg[192 + row];
+            rseg[mt][r] = __float_as_int(ri[row * 4]);
+        }
+    if (EQUIV) {
+        if (wid != 0) return;
+        for (int s = 0; s < nseg; ++s) {
+            float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sel[mt][r] = rseg[mt][r] == (c >> 2) + 4 * (c & 3) ? mcg_sigmoid(dot[mt][r] + p.bv) : 0.f;
-            f32x4 d[NSW];
-#pragma unroll
-            for (int i = 0; i < NSW; ++i) d[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if constexpr (SPLIT == 1) {
-                // bf16 mode: the segmented, gate-scaled sum is ONE MORE bf16 contraction (D[seg][col] = sum_row S[seg][row] m[row][col],
-                // S = gate or 0): its operands - the gate and the message - are rounded to bf16 like the operands of every other
-                // MFMA of the mode, fp32 accumulate; 2 x 16-cycle MFMAs per column tile instead of 16 x 32 on the fp32 pipe.
-                // Contraction slot j of lane group g stands for row (tile 2h + j/4, 4g + j%4) on BOTH operands, so the B operand is
-                // just the lane's own accumulator registers of the two row tiles and the A operand its own gate values.
-                // (Rounds 1-4 carried both operands as hi + lo pairs and issued three products per tile pair (relative error
-                //  2^-16): 280 more VALU instructions and 28 more MFMAs per wave in the kernel's instruction-heaviest part for
-                //  precision the next consumer - the node GEMM, which rounds the aggregate to bf16 - throws away; measured at the
-                //  256-ragged shape: 146.3 -> 140.5 us per launch, deviation from the bf16 emulation / the fp32 path unchanged
-                //  (7.4e-4 / 1.2e-3 -> 8.1e-4 / 1.1e-3 of max|out|; profiles/round5_probes.txt).)
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    bf16x8 g_hi;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) g_hi[j] = (__bf16)sel[2 * h2 + (j >> 2)][j & 3];
-#pragma unroll
-                    for (int i = 0; i < NSW; ++i) {
-                        bf16x8 m_hi;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) m_hi[j] = (__bf16)acc[4 * u + 2 * h2 + (j >> 2)][i][j & 3];
-                        d[i] = mcg_mfma_bf16(g_hi, m_hi, d[i]);
-                    }
-                }
-            } else {
-                // split-operand modes keep this sum exact (fp32 MFMA).  The 16 MFMAs of one column tile are a dependent
-                // chain: run the wave's chains interleaved
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int i = 0; i < NSW; ++i) d[i] = mcg_mfma(sel[mt][t], acc[4 * u + mt][i][t], d[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < NSW; ++i) {
-                const int nt = wid + WAVES * i;
-                if (nt >= NT) continue;
-#pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (4 * r < nseg && g + 4 * r < nseg) p.P[(size_t)(pbase + g + 4 * r) * HP + nt * 16 + c] = d[i][r];
+                    if (rseg[mt][r] == s) {
+                        const float* q = ri + (16 * mt + 4 * g + r) * 4;
+                        sx += q[1] * dot[mt][r]; sy += q[2] * dot[mt][r]; sz += q[3] * dot[mt][r];
+                    }
+            // each row is held by the 16 lanes of one lane group: divide the 16 identical copies out by summing
+            // over lane groups only (lanes with c == 0 carry the value)
+            sx = mcg_group4_sum(sx); sy = mcg_group4_sum(sy); sz = mcg_group4_sum(sz);
+            if (lane == 0) {
+                float* dst = p.P + (size_t)(pbase + s) * 4;
+                dst[0] = sx; dst[1] = sy; dst[2] = sz; dst[3] = 0.f;
             }
+        }
+    } else {
+        float sel[4][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sel[mt][r] = rseg[mt][r] == (c >> 2) + 4 * (c & 3) ? mcg_sigmoid(dot[mt][r] + p.bv) : 0.f;
+        f32x4 d[NS_T];
+#pragma unroll
+        for (int i = 0; i < NS_T; ++i) d[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (SPLIT == 1) {
+            // bf16 mode: the segmented, gate-scaled sum is ONE MORE bf16 contraction (D[seg][col] = sum_row S[seg][row] m[row][col],
+            // S = gate or 0): its operands - the gate and the message - are rounded to bf16 like the operands of every other
+            // MFMA of the mode, fp32 accumulate; 2 x 16-cycle MFMAs per column tile instead of 16 x 32 on the fp32 pipe.
+            // Contraction slot j of lane group g stands for row (tile 2h + j/4, 4g + j%4) on BOTH operands, so the B operand is
+            // just the lane's own accumulator registers of the two row tiles and the A operand its own gate values.
+            // (Rounds 1-4 carried both operands as hi + lo pairs and issued three products per tile pair (relative error
+            //  2^-16): 280 more VALU instructions and 28 more MFMAs per wave in the kernel's instruction-heaviest part for
+            //  precision the next consumer - the node GEMM, which rounds the aggregate to bf16 - throws away; measured at the
+            //  256-ragged shape: 146.3 -> 140.5 us per launch, deviation from the bf16 emulation / the fp32 path unchanged
+            //  (7.4e-4 / 1.2e-3 -> 8.1e-4 / 1.1e-3 of max|out|; profiles/round5_probes.txt).)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                bf16x8 g_hi;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g_hi[j] = (__bf16)sel[2 * h2 + (j >> 2)][j & 3];
+#pragma unroll
+                for (int i = 0; i < NS_T; ++i) {
+                    bf16x8 m_hi;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) m_hi[j] = (__bf16)acc[2 * h2 + (j >> 2)][i][j & 3];
+                    d[i] = mcg_mfma_bf16(g_hi, m_hi, d[i]);
+                }
+            }
+        } else {
+            // split-operand modes keep this sum exact (fp32 MFMA).  The 16 MFMAs of one column tile are a dependent
+            // chain: run the wave's 7 chains interleaved
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < NS_T; ++i) d[i] = mcg_mfma(sel[mt][t], acc[mt][i][t], d[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NS_T; ++i) {
+            const int nt = wid + 4 * i;
+            if (nt >= NT) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * r < nseg && g + 4 * r < nseg) p.P[(size_t)(pbase + g + 4 * r) * HP + nt * 16 + c] = d[i][r];
         }
     }
 }
@@ -706,16 +617,9 @@ hipError_t mcg_launch_edge_bf16_16(const EdgeArgs& a, bool equiv, hipStream_t s,
     return equiv ? edge_launch(k_edge_lds_bf16<true>, wgs, s, a, t0, t1) : edge_launch(k_edge_lds_bf16<false>, wgs, s, a, t0, t1);
 }
 
-// a.n_waves = 64-row units of an edge_mt = 4 plan; a.Bp = bf16 pack (x6 = false) or three-part pack (x6 = true).
-// `pair` (bf16 mode only): eight-wave workgroups over two consecutive units each (k_edge_bf16_w64<.., U = 2>).
-hipError_t mcg_launch_edge_w64(const EdgeArgs& a, bool equiv, bool x6, hipStream_t s, hipEvent_t t0, hipEvent_t t1, bool pair) {
+// a.n_waves = 64-row units of an edge_mt = 4 plan; a.Bp = bf16 pack (x6 = false) or three-part pack (x6 = true)
+hipError_t mcg_launch_edge_w64(const EdgeArgs& a, bool equiv, bool x6, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
     if (x6) return equiv ? edge_launch(k_edge_bf16_w64<true, 3>, a.n_waves, s, a, t0, t1) : edge_launch(k_edge_bf16_w64<false, 3>, a.n_waves, s, a, t0, t1);
-    if (pair) {
-        const int wgs = (a.n_waves + 1) / 2;
-        if (a.pab_blocked)
-            return equiv ? edge_launch(k_edge_bf16_w64<true, 1, true, 2>, wgs, s, a, t0, t1, 512) : edge_launch(k_edge_bf16_w64<false, 1, true, 2>, wgs, s, a, t0, t1, 512);
-        return equiv ? edge_launch(k_edge_bf16_w64<true, 1, false, 2>, wgs, s, a, t0, t1, 512) : edge_launch(k_edge_bf16_w64<false, 1, false, 2>, wgs, s, a, t0, t1, 512);
-    }
     if (a.pab_blocked)
         return equiv ? edge_launch(k_edge_bf16_w64<true, 1, true>, a.n_waves, s, a, t0, t1) : edge_launch(k_edge_bf16_w64<false, 1, true>, a.n_waves, s, a, t0, t1);
     return equiv ? edge_launch(k_edge_bf16_w64<true, 1>, a.n_waves, s, a, t0, t1) : edge_launch(k_edge_bf16_w64<false, 1>, a.n_waves, s, a, t0, t1);

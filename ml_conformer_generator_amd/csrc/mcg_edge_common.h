@@ -81,12 +81,12 @@ __device__ __forceinline__ f32x4 edge_agen4(const f32x4& va, const f32x4& vb, co
     return (f32x4){lo[0], lo[1], hi[0], hi[1]};
 }
 
-// one launch of an edge kernel (256 threads per workgroup unless said otherwise); with `t0` / `t1` the kernel's own begin /
-// end timestamps are recorded into the two events (what a kernel trace reports as its duration)
+// one launch of an edge kernel (256 threads per workgroup); with `t0` / `t1` the kernel's own begin / end timestamps
+// are recorded into the two events (what a kernel trace reports as its duration)
 template <class K>
-hipError_t edge_launch(K kernel, int grid, hipStream_t s, const EdgeArgs& a, hipEvent_t t0, hipEvent_t t1, int threads = 256) {
-    if (t0 && t1) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(threads), 0, s, t0, t1, 0, a);
-    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), 0, s, a);
+hipError_t edge_launch(K kernel, int grid, hipStream_t s, const EdgeArgs& a, hipEvent_t t0, hipEvent_t t1) {
+    if (t0 && t1) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, s, t0, t1, 0, a);
+    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -180,17 +180,8 @@ static bool edge_wgc(const mcg_egnn* m, const mcg_plan* pl) {
 #ifndef MCG_PAB_BLOCKED
 #define MCG_PAB_BLOCKED 1          // (measurement switch: 0 = row-major layer-1 inputs in the bf16 mode too)
 #endif
-// bf16 mode, 64-row plans: eight-wave workgroups over two units each (k_edge_bf16_w64<.., U = 2>: the W2 stream per CU halves)
-// from MCG_EDGE_PAIR_MIN_UNITS units on - below that the 4-wave workgroups fill the chip better; MCG_OPT_EDGE_BF16_PAIR overrides
-#ifndef MCG_EDGE_PAIR_MIN_UNITS
-#define MCG_EDGE_PAIR_MIN_UNITS 1024
-#endif
-static bool edge_pair(const mcg_egnn* m, const mcg_plan* pl) {
-    if (!m || !m->bf16 || pl->MT != 4 || m->edge_bf16_pair == 1) return false;
-    return m->edge_bf16_pair == 2 || pl->n_waves >= MCG_EDGE_PAIR_MIN_UNITS;
-}
 int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipStream_t s, bool bf16 = false, bool x6 = false,
-             bool wgc = false, bool pair = false) {
+             bool wgc = false) {
     if (pl->n_waves == 0) return MCG_OK;
     EdgeArgs a;
     a.pab = pl->pab; a.x = pl->x; a.x0 = pl->x0; a.wd = L.wd; a.wd0 = L.wd0; a.Bp = L.w2_Bp; a.b2 = L.b2;
@@ -217,7 +208,7 @@ int run_edge(const mcg_plan* pl, const EdgeLayer& L, bool equiv, float* P, hipSt
     }
     if (bf16) {
         a.Bp = reinterpret_cast<const float*>(L.w2_Bp16);
-        if (pl->MT == 4) MCG_HIP(mcg_launch_edge_w64(a, equiv, false, s, t0, t1, pair));
+        if (pl->MT == 4) MCG_HIP(mcg_launch_edge_w64(a, equiv, false, s, t0, t1));
         else MCG_HIP(mcg_launch_edge_bf16_16(a, equiv, s, t0, t1));
         return MCG_OK;
     }
@@ -312,7 +303,7 @@ int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s, bool keep
                      MCG_ACT_NONE, s, lp ? E.pab_Bp16 : nullptr, x6g ? E.pab_Bp16x3 : nullptr, pl, pab_rows16(M), nullptr, 2, m,
                      lp && pl->MT == 4 && MCG_PAB_BLOCKED)) return e;          // (bf16, 64-row units: pab in the blocked layout the edge kernel reads)
     if (int e = apply_pending_x(pl, s)) return e;              // (only if the GEMM above could not carry it)
-    if (int e = run_edge(pl, E, false, pl->P, s, lp, m->x6, wgc, edge_pair(m, pl))) return e;
+    if (int e = run_edge(pl, E, false, pl->P, s, lp, m->x6, wgc)) return e;
     const int4* gather = nullptr;
     if (wgc && f32 && !keep_agg) {
         gather = pl->units().node_slots;                        // the node GEMM adds an atom's rows of U itself
@@ -346,7 +337,7 @@ int run_equiv(const mcg_egnn* m, mcg_plan* pl, int block, hipStream_t s) {
     if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
                      MCG_ACT_NONE, s, m->bf16 ? E.pab_Bp16 : nullptr, (m->x6 && m->x6_gemm) ? E.pab_Bp16x3 : nullptr, nullptr,
                      pab_rows16(M), nullptr, 2, m, m->bf16 && pl->MT == 4 && MCG_PAB_BLOCKED)) return e;
-    if (int e = run_edge(pl, E, true, pl->Px, s, m->bf16, m->x6, wgc, edge_pair(m, pl))) return e;
+    if (int e = run_edge(pl, E, true, pl->Px, s, m->bf16, m->x6, wgc)) return e;
     if (wgc) {
         pl->x_pending = true;          // applied by the next launch that can carry it (next block's first GEMM / k_output)
         pl->pending_u = pl->Ux; pl->pending_slots = pl->units().node_slots;
@@ -489,7 +480,7 @@ int mcg_bench_edge(const mcg_egnn* m, mcg_plan* pl, int layer, int equiv, int it
     mcg_plan_mark_guard done{pl, (hipStream_t)stream};
     for (int i = 0; i < iters; ++i)
         if (int e = run_edge(pl, equiv ? m->equiv[layer] : m->gcl_edge[layer], equiv != 0, equiv ? pl->Px : pl->P,
-                             (hipStream_t)stream, m->bf16, m->x6, edge_wgc(m, pl), edge_pair(m, pl))) return e;
+                             (hipStream_t)stream, m->bf16, m->x6, edge_wgc(m, pl))) return e;
     return MCG_OK;
 }
 

@@ -68,8 +68,7 @@ struct EdgeArgs {
 hipError_t mcg_launch_edge_exact(const EdgeArgs& a, bool equiv, int n_units, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);   // k_edge_lds: four-tile + quarter-tile units
 hipError_t mcg_launch_edge_ns(const EdgeArgs& a, bool equiv, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);                    // k_edge_ns: one workgroup per 16-row tile
 hipError_t mcg_launch_edge_bf16_16(const EdgeArgs& a, bool equiv, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);               // k_edge_lds_bf16: 16 rows per wave
-hipError_t mcg_launch_edge_w64(const EdgeArgs& a, bool equiv, bool x6, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr,
-                               bool pair = false);          // k_edge_bf16_w64: 64-row units, bf16 / f32x6; pair: 8-wave workgroups over two units (bf16)
+hipError_t mcg_launch_edge_w64(const EdgeArgs& a, bool equiv, bool x6, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);          // k_edge_bf16_w64: 64-row units, bf16 / f32x6
 
 struct EdgeLayer {      // second layer + head of an edge MLP, and its factorised first layer
     float *pab_Bp = nullptr, *pab_bias = nullptr, *wd = nullptr, *wd0 = nullptr;
@@ -95,7 +94,6 @@ struct mcg_egnn {
     bool x6_gemm = true;        // f32x6 mode: node-side GEMMs on the split-operand kernel too
     int gemm_rn = 0, gemm_x6_rn = 0;   // wave tile width of the node GEMMs (0 = the launcher's cost model)
     int gemm_bf16_lds = 0;             // MCG_OPT_GEMM_BF16_LDS: 0 auto, 1 never, 2 whenever the shape allows
-    int edge_bf16_pair = 0;            // MCG_OPT_EDGE_BF16_PAIR: 0 auto (large plans), 1 never, 2 always - 8-wave workgroups over two 64-row units
     uint32_t opt_epoch = 0;     // bumped by mcg_egnn_set_precision / mcg_egnn_set_option: part of the captured graph's key,
                                 // so a plan that already captured its launches re-captures after a change
     float *emb_wT = nullptr, *emb_b = nullptr, *out_w = nullptr, *out_b = nullptr;

@@ -14,7 +14,7 @@ import torch
 from conftest import GOLDEN as GOLD
 from conftest import REPO, TapeNoise, load_golden, sd_for
 from parity_tolerance import close as _close
-from parity_tolerance import traj_violation, violation
+from parity_tolerance import LONG_TRAJ_REL, traj_violation, violation
 
 pytestmark = pytest.mark.gpu
 
@@ -521,7 +521,9 @@ def test_sampler_at_the_judged_step_counts_vs_reference_golden(sampler_factory):
     recorded tapes at those lengths (`tools/make_golden.py` section 10: contractive weights, a one-ulp change of the
     context moves the reference's own final x by 3e-7 / 6e-7 of max|x|): same number and order of noise draws, every
     recorded latent (each 10th / 50th step) and the final x within the stated trajectory tolerance (1e-3 of the step's own
-    channel-group magnitude), atom types exact."""
+    channel-group magnitude), atom types exact.
+    Round 6: held to LONG_TRAJ_REL = 1e-5 instead of the 1e-3 of the short full-gain trajectories - the mutation check of these
+    two contractive fixtures (profiles/round6_parity_sensitivity.txt) needs it, and the fp32 kernels follow them to 7e-7."""
     g = load_golden("e2e_T100_b2n27.npz")
     nm = g["node_mask"]
     gm = sampler_factory(int(g["T"]), g, "f32")
@@ -529,9 +531,9 @@ def test_sampler_at_the_judged_step_counts_vs_reference_golden(sampler_factory):
     gm.trace = []
     x, h = gm(nm.to(DEV), edge_mask_of(nm).to(DEV), g["context"].to(DEV), 0)
     assert gm.noise_fn.pos == g["noise"].numel() and len(gm.trace) == 100
-    v = traj_violation(torch.stack(gm.trace).cpu()[g["z_trace_index"].long()], g["z_trace"])
+    v = traj_violation(torch.stack(gm.trace).cpu()[g["z_trace_index"].long()], g["z_trace"], rel=LONG_TRAJ_REL)
     assert v <= 1.0, f"T = 100 trajectory at {v} x tolerance"
-    vx = traj_violation(x.cpu().unsqueeze(0), g["x"].unsqueeze(0), split=None)
+    vx = traj_violation(x.cpu().unsqueeze(0), g["x"].unsqueeze(0), rel=LONG_TRAJ_REL, split=None)
     assert vx <= 1.0 and torch.equal(h.cpu().to(torch.int64), g["h"].to(torch.int64))
     print(f"T=100: worst recorded latent at {v:.3f} x tolerance, final x at {vx:.3f} (reference amplification of one ulp: "
           f"{float(g['one_ulp_context_rel_dev']):.1e})")
@@ -543,9 +545,9 @@ def test_sampler_at_the_judged_step_counts_vs_reference_golden(sampler_factory):
     gm.trace = []
     x, h = gm.inpaint(nm.to(DEV), edge_mask_of(nm).to(DEV), g["context"].to(DEV), g["z_known"], g["fixed_mask"], 1, 3)
     assert gm.noise_fn.pos == g["noise"].numel() and len(gm.trace) == int(g["n_sampler_steps"])
-    v = traj_violation(torch.stack(gm.trace).cpu()[g["z_trace_index"].long()], g["z_trace"])
+    v = traj_violation(torch.stack(gm.trace).cpu()[g["z_trace_index"].long()], g["z_trace"], rel=LONG_TRAJ_REL)
     assert v <= 1.0, f"T = 250 inpainting trajectory at {v} x tolerance"
-    vx = traj_violation(x.cpu().unsqueeze(0), g["x"].unsqueeze(0), split=None)
+    vx = traj_violation(x.cpu().unsqueeze(0), g["x"].unsqueeze(0), rel=LONG_TRAJ_REL, split=None)
     assert vx <= 1.0 and torch.equal(h.cpu().to(torch.int64), g["h"].to(torch.int64))
     print(f"T=250 rs=1: worst recorded latent at {v:.3f} x tolerance, final x at {vx:.3f}")
     gm.noise_fn, gm.trace = None, None
@@ -601,8 +603,8 @@ def test_config5_bf16_inpaint_vs_bf16_emulated_sampler():
 #                                                              sampler's own 1/alpha_ts amplification and the contractive weights)
 #   vs the bf16-operand emulation         BF16_TRAJ_REL_EMU   (same roundings, different accumulation order / rounding flips)
 # The measured deviations are written to gpurun_out/round6_bf16_judged_lengths.txt (committed as profiles/round6_bf16_judged_lengths.txt).
-BF16_TRAJ_REL_REF = 2e-2
-BF16_TRAJ_REL_EMU = 1e-2
+BF16_TRAJ_REL_REF = 5e-3          # measured worst 1.03e-3 (T = 250, step 99), 2.2e-4 (T = 100): profiles/round6_bf16_judged_lengths.txt
+BF16_TRAJ_REL_EMU = 1e-3          # measured worst 1.9e-4 / 4.7e-6
 
 
 def _per_latent_rel_dev(a, b):
@@ -2151,93 +2153,3 @@ def test_bf16_mode_gathers_partial_sums_in_the_node_gemm(edm_sd):
             assert (int(c[1][7]) > 0) == (lds == 2), (small, lds, c)
         assert torch.equal(res[0], res[1]), small
     _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_GEMM_BF16_LDS, 0), "mcg_egnn_set_option")
-
-
-@pytest.mark.gpu
-def test_bf16_eight_wave_edge_workgroups_are_bit_identical_to_four_wave_ones(edm_sd):
-    """Round 6: bf16 mode, 64-row plans - one EIGHT-wave workgroup over two consecutive 64-row units (`k_edge_bf16_w64<.., U = 2>`:
-    the waves split the 27 column tiles eight ways, every W2 fragment feeds eight MFMAs, the weight stream per CU halves)
-    against the four-wave workgroup per unit.  Same operand values, same k order, and the gate / coordinate-head dot product
-    is summed in an order both geometries produce (column-tile residue classes mod 8): the whole denoiser call must not change
-    a bit - ragged batches with an ODD number of units (the last workgroup's second half is padding), a single unit, tiny
-    molecules, one GCL layer's partial sums and the coordinate layer, the automatic choice above its threshold - and both
-    stay within the stated bf16 tolerances of the emulation-anchored fp32 oracle."""
-    from ml_conformer_generator_amd import _lib
-    from ml_conformer_generator_amd.egnn import EGNNDynamics
-    from oracle import egnn_oracle as EO
-    from oracle import host_oracle as HO
-    L = _lib.lib()
-    d = EGNNDynamics(device=DEV)
-    d.load_reference_state_dict(edm_sd)
-    d.set_precision("bf16")
-    g = torch.Generator().manual_seed(606)
-
-    def both(sizes, n_ranges=1, t_val=0.4):
-        sz = torch.tensor(sizes)
-        N = int(sz.max())
-        nm = (torch.arange(N).unsqueeze(0) < sz.unsqueeze(1)).float().unsqueeze(2)
-        z = (torch.randn(len(sizes), N, 11, generator=g) * nm)
-        ctx = (torch.randn(len(sizes), 1, 3, generator=g).repeat(1, N, 1) * nm)
-        t = torch.full((len(sizes),), t_val)
-        plan = d.plan(sz, N, n_ranges=n_ranges)
-        assert plan.edge_mt == 4
-        outs = []
-        for pair in (1, 2):
-            d.set_option(_lib.OPT_EDGE_BF16_PAIR, pair)
-            outs.append(d.run(plan, t.to(DEV), z.to(DEV), ctx.to(DEV)).clone())
-        d.set_option(_lib.OPT_EDGE_BF16_PAIR, 0)
-        assert torch.equal(outs[0], outs[1]), (sizes[:6], len(sizes), n_ranges, float((outs[0] - outs[1]).abs().max()))
-        assert bool(torch.isfinite(outs[1]).all())
-        return plan, sz, N, nm, z, ctx, t, outs[1]
-
-    # one unit (the pair's second half is padding), two units, an odd number, tiny molecules, the largest ones
-    for sizes in ([9], [8, 9], [15, 19, 17], [6] * 11, [39, 39, 38], [27] * 7, [6, 7, 39, 8, 25]):
-        plan, *_ = both(sizes)
-    sizes = torch.randint(15, 40, (96,), generator=g).tolist()
-    seen_parity = set()
-    for drop in range(16):                      # unit counts of both parities (dropping a molecule moves the count)
-        plan, sz, N, nm, z, ctx, t, out = both(sizes[:len(sizes) - drop])
-        seen_parity.add(plan.n_edge_waves % 2)
-        if seen_parity == {0, 1} and drop >= 2:
-            break
-    assert seen_parity == {0, 1}
-    both(sizes, n_ranges=2)
-    # against the fp32 oracle (stated bf16 tolerance of one denoiser call: 3e-2 of max|out|) - a ragged subset the CPU finishes in seconds
-    sub = sizes[:6]
-    _, sz6, N6, nm6, z6, ctx6, t6, out6 = both(sub)
-    em6 = HO.masks_from_sizes(sz6, N6)[1]
-    ref = EO.egnn_dynamics(edm_sd, t6.reshape(-1, 1), z6, nm6, em6, ctx6)
-    assert float((out6.cpu() - ref).abs().max()) <= 3e-2 * float(ref.abs().max())
-    emu = _egnn_dynamics_bf16_emulated(edm_sd, t6.reshape(-1, 1), z6, nm6, em6, ctx6)
-    assert float((out6.cpu() - emu).abs().max()) <= 3e-3 * float(emu.abs().max())
-    # one GCL layer and one whole block (coordinate layer incl.) through the debug hooks: partial sums, aggregate, h, x
-    M = plan.n_real_nodes
-    h0 = torch.randn(M, 420, generator=g).to(DEV)
-    x0 = (torch.randn(M, 3, generator=g) * 2).to(DEV)
-    res = []
-    for pair in (1, 2):
-        d.set_option(_lib.OPT_EDGE_BF16_PAIR, pair)
-        gd = d.gcl_debug(plan, 0, h0, x0, x0)
-        hb, xb = d.block_debug(plan, 0, h0, x0, x0)
-        res.append((gd["h_out"].clone(), gd["agg"].clone() if "agg" in gd else gd["h_out"], hb.clone(), xb.clone()))
-    d.set_option(_lib.OPT_EDGE_BF16_PAIR, 0)
-    for a, b in zip(*res):
-        assert torch.equal(a, b)
-    # the automatic choice: eight-wave workgroups from MCG_EDGE_PAIR_MIN_UNITS (1 024) units on - same bits again
-    big = torch.randint(15, 40, (112,), generator=g).tolist()
-    szb = torch.tensor(big)
-    Nb = int(szb.max())
-    nmb = (torch.arange(Nb).unsqueeze(0) < szb.unsqueeze(1)).float().unsqueeze(2)
-    zb = (torch.randn(len(big), Nb, 11, generator=g) * nmb).to(DEV)
-    cb = (torch.randn(len(big), 1, 3, generator=g).repeat(1, Nb, 1) * nmb).to(DEV)
-    tb = torch.full((len(big),), 0.7, device=DEV)
-    planb = d.plan(szb, Nb, n_ranges=1)
-    assert planb.n_edge_waves >= 1024
-    got = []
-    for pair in (0, 1, 2):
-        d.set_option(_lib.OPT_EDGE_BF16_PAIR, pair)
-        got.append(d.run(planb, tb, zb, cb).clone())
-    d.set_option(_lib.OPT_EDGE_BF16_PAIR, 0)
-    assert torch.equal(got[0], got[1]) and torch.equal(got[1], got[2])
-    with pytest.raises(RuntimeError):
-        d.set_option(_lib.OPT_EDGE_BF16_PAIR, 3)

@@ -31,7 +31,7 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 from ml_conformer_generator_amd import weights as W      # noqa: E402
 from oracle import diffusion_oracle as DO                # noqa: E402
 from oracle import egnn_oracle as EO                     # noqa: E402
-from parity_tolerance import traj_violation, violation   # noqa: E402
+from parity_tolerance import LONG_TRAJ_REL, traj_violation, violation   # noqa: E402
 
 MIN_RATIO = 10.0
 GOLD = os.path.join(REPO, "tests", "golden")
@@ -75,8 +75,16 @@ class TapeNoise:
         return out
 
 
-def run_fixture(name, g, sd, gain_sd_cache={}):
-    """-> violation ratio of the oracle run with weights `sd` against the fixture's reference output(s)."""
+LONG = ("e2e_T100", "inpaint_T250")      # the judged-length fixtures: held to LONG_TRAJ_REL (tests/parity_tolerance.py)
+
+
+class _Enough(Exception):
+    pass
+
+
+def run_fixture(name, g, sd, kept=None):
+    """-> violation ratio of the oracle run with weights `sd` against the fixture's reference output(s), under the tolerance
+    the GPU tests hold that fixture to.  `kept`: judged-length fixtures only - stop behind the kept-th recorded latent."""
     if name.startswith("dynamics_"):
         nm = g["node_mask"]
         out = EO.egnn_dynamics(sd, g["t"], g["xh"], nm, edge_mask_of(nm), g["context"])
@@ -93,19 +101,32 @@ def run_fixture(name, g, sd, gain_sd_cache={}):
     # sampler fixtures
     T = int(g["T"])
     orc = DO.SamplerOracle(sd, T, noise_fn=TapeNoise(g["noise"]))
-    orc.trace = []
+    idx = g["z_trace_index"].long() if "z_trace_index" in g else None      # the judged-length fixtures keep every 10th / 50th latent only
+    n_keep = None if idx is None else (idx.numel() if kept is None else min(kept, idx.numel()))
+    stop_after = None if (idx is None or n_keep == idx.numel()) else int(idx[n_keep - 1]) + 1
+
+    class _Trace(list):
+        def append(self, z):
+            super().append(z)
+            if stop_after is not None and len(self) >= stop_after:
+                raise _Enough
+
+    orc.trace = _Trace()
     nm = g["node_mask"]
     em = edge_mask_of(nm)
-    if name.startswith("sampler") or name.startswith("e2e_T100"):
-        orc.forward(nm, em, g["context"], int(g["resample_steps"]))
-    elif name.startswith("inpaint"):
-        orc.inpaint(nm, em, g["context"], g["z_known"], g["fixed_mask"], int(g["resample_steps"]), int(g["blend_power"]))
-    else:
-        orc.merge_fragments(nm, em, g["fixed_mask"], g["context"], g["z_known"], int(g["diffusion_level"]),
-                            int(g["resample_steps"]), int(g["blend_power"]))
-    zt = torch.stack(orc.trace)
-    if "z_trace_index" in g:                       # the judged-length fixtures keep every 10th / 50th latent only
-        zt = zt[g["z_trace_index"].long()]
+    try:
+        if name.startswith("sampler") or name.startswith("e2e_T100"):
+            orc.forward(nm, em, g["context"], int(g["resample_steps"]))
+        elif name.startswith("inpaint"):
+            orc.inpaint(nm, em, g["context"], g["z_known"], g["fixed_mask"], int(g["resample_steps"]), int(g["blend_power"]))
+        else:
+            orc.merge_fragments(nm, em, g["fixed_mask"], g["context"], g["z_known"], int(g["diffusion_level"]),
+                                int(g["resample_steps"]), int(g["blend_power"]))
+    except _Enough:
+        pass
+    zt = torch.stack(list(orc.trace))
+    if idx is not None:
+        return traj_violation(zt[idx[:n_keep]], g["z_trace"][:n_keep], rel=LONG_TRAJ_REL if name.startswith(LONG) else 1e-3)
     return traj_violation(zt, g["z_trace"])
 
 
@@ -129,6 +150,9 @@ def main():
                     help="the two judged-length fixtures only (round 6): e2e_T100_b2n27 (101 denoiser calls per run) and "
                          "inpaint_T250_rs1_b2 (501 calls per run) - ~40 min of an 8-core host for the 38 mutations of each")
     ap.add_argument("--threads", type=int, default=min(8, os.cpu_count() or 1))
+    ap.add_argument("--kept", type=int, default=3,
+                    help="--long: replay inpaint_T250_rs1_b2 up to this many kept latents only (3 = 150 of its 500 sampler steps, where "
+                         "its deviations peak; 10 = all of it, 3.3 x the time); e2e_T100 always runs in full")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     names = ["dynamics_b2n20.npz", "dynamics_b4n19.npz", "dynamics_b3n39.npz", "dynamics_b3n27_x30.npz", "block3_b2n20.npz"]
@@ -143,10 +167,13 @@ def main():
         for name in names:
             g = load(name)
             sd = fixture_weights(g)
-            base = run_fixture(name, g, sd)
+            kept = args.kept if name.startswith("inpaint_T250") else None
+            base = run_fixture(name, g, sd, kept)
             status = "ok" if base <= 1.0 else "ORACLE OUTSIDE TOLERANCE"
             bad += base > 1.0
-            print(f"{name:28s} unmutated oracle vs reference: {base:8.3f} x tolerance  {status}", flush=True)
+            tol = f"{LONG_TRAJ_REL:g} (LONG_TRAJ_REL)" if name.startswith(LONG) else "the per-call / 1e-3 trajectory tolerance"
+            print(f"{name:28s} unmutated oracle vs reference: {base:8.3f} x tolerance  {status}   [tolerance: {tol}"
+                  + (f"; first {kept} kept latents" if kept else "") + "]", flush=True)
             blocks = (3,) if name.startswith("block") else (0, 4, 8)
             worst = None
             for label, key, fn in mutations(blocks):
@@ -154,13 +181,13 @@ def main():
                     continue
                 sdm = dict(sd)
                 sdm[key] = fn(sd[key].clone())
-                r = run_fixture(name, g, sdm)
+                r = run_fixture(name, g, sdm, kept)
                 # the attention BIAS only moves a gate that is not saturated: required to show on the unit-scale
                 # single-call / block fixtures, informational where |z| is large (x30 inputs, sampler trajectories)
                 required = not (label.startswith("zero_attb") and ("x30" in name or not (name.startswith("dynamics_") or name.startswith("block"))))
                 flag = "" if r >= MIN_RATIO else ("   <-- BLIND" if required else "   (informational)")
                 bad += required and r < MIN_RATIO
-                print(f"    {label:22s} {r:12.1f} x tolerance{flag}", flush=True)
+                print(f"    {label:22s} {r:12.2f} x tolerance{flag}", flush=True)
                 if required:
                     worst = r if worst is None else min(worst, r)
             print(f"    -> least visible required mutation: {worst:.1f} x tolerance")
