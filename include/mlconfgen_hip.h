@@ -56,15 +56,19 @@ int mcg_egnn_set_precision(mcg_egnn* m, int mode);
  *   MCG_OPT_GEMM_RN     [0]  wave tile width (column tiles) of the 32-row node GEMM kernel: 0 = cost model, 1..3
  *   MCG_OPT_GEMM_X6_RN  [0]  same for the split-operand GEMM kernel
  *   MCG_OPT_GEMM_BF16_LDS [0] bf16 mode: 0 = the LDS-staged 9-wave node GEMM from 80 row blocks (2 560 atoms) on, 1 = never (32-row kernel),
- *                            2 = whenever its shape limits allow (results are bit-identical either way) */
-enum { MCG_OPT_X6_GEMM = 1, MCG_OPT_GEMM_RN = 2, MCG_OPT_GEMM_X6_RN = 3, MCG_OPT_GEMM_BF16_LDS = 4 };
+ *                            2 = whenever its shape limits allow (results are bit-identical either way)
+ *   MCG_OPT_NODE_FUSED  [0]  bf16 mode: the node phase of a GCL layer (node MLP + the next edge layer's first-layer projections) as ONE
+ *                            launch: 0 = from 32 row blocks (1 024 atoms) on, 1 = never (three launches),
+ *                            2 = whenever the bf16 gather path runs (results are bit-identical either way) */
+enum { MCG_OPT_X6_GEMM = 1, MCG_OPT_GEMM_RN = 2, MCG_OPT_GEMM_X6_RN = 3, MCG_OPT_GEMM_BF16_LDS = 4, MCG_OPT_NODE_FUSED = 5 };
 /* Both setters may be called at any time between denoiser calls: a plan that has already captured its launches as a HIP
  * graph re-captures on its next call (the graph is keyed by the model's option epoch). */
 int mcg_egnn_set_option(mcg_egnn* m, int option, int value);
 
 /* Measurement / test hook: node and GCN GEMM launches ISSUED (plainly or into a graph capture) by this process since the
  * last reset, counts_host[family * 8 + rn] with family 0 = 32-row fp32 kernel, 1 = 32-row bf16 kernel, 2 = 16-row-tile fp32
- * kernel, 3 = split-operand kernel and rn = column tiles per wave (family 1, slot 7 = the LDS-staged 9-wave bf16 kernel) - how a
+ * kernel, 3 = split-operand kernel and rn = column tiles per wave (family 1: slot 7 = the LDS-staged 9-wave bf16 kernel, slot 6 = the
+ * fused node launch of MCG_OPT_NODE_FUSED) - how a
  * test sees that an option changed launch shapes. */
 int mcg_debug_gemm_launches(int64_t* counts_host, int reset);
 

@@ -63,7 +63,7 @@ class PlanOpts(C.Structure):
 
 
 ALL_FOUR_TILE = 0x3fffffff          # MCG_ALL_FOUR_TILE
-OPT_X6_GEMM, OPT_GEMM_RN, OPT_GEMM_X6_RN, OPT_GEMM_BF16_LDS = 1, 2, 3, 4
+OPT_X6_GEMM, OPT_GEMM_RN, OPT_GEMM_X6_RN, OPT_GEMM_BF16_LDS, OPT_NODE_FUSED = 1, 2, 3, 4, 5
 
 _lib = None
 

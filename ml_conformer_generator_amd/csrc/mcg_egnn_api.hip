@@ -2,6 +2,7 @@
 // (egnn.py:188-222: two GCL layers + the coordinate update; node GEMMs of mcg_gemm.h around the fused edge kernels of
 // mcg_edge_*.hip), output head; captured once per plan as a HIP graph and replayed.  Debug / measurement hooks.
 #include "mcg_gemm.h"
+#include "mcg_node_fused.h"
 #include "mcg_egnn_internal.h"
 
 #include <atomic>
@@ -299,11 +300,31 @@ int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s, bool keep
     // (a pending coordinate update of the previous block rides along with this launch; the split-operand GEMM kernel has
     //  no side job: apply it first)
     if (x6g) { if (int e = apply_pending_x(pl, s)) return e; }
-    if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
-                     MCG_ACT_NONE, s, lp ? E.pab_Bp16 : nullptr, x6g ? E.pab_Bp16x3 : nullptr, pl, pab_rows16(M), nullptr, 2, m,
-                     lp && pl->MT == 4 && MCG_PAB_BLOCKED)) return e;          // (bf16, 64-row units: pab in the blocked layout the edge kernel reads)
+    const bool blocked = lp && pl->MT == 4 && MCG_PAB_BLOCKED;   // (bf16, 64-row units: pab in the blocked layout the edge kernel reads)
+    // bf16 mode, large batches (round 6): W3 -> SiLU -> W4 -> + h -> the NEXT edge layer's first-layer projections in ONE launch
+    // (mcg_node_fused.h) where the three launches would all be the LDS-staged 9-wave kernel; bit-identical h and Pab
+    // (from MCG_NF_MIN_ROWBLOCKS row blocks on: ms per denoiser call, three launches -> one, 27-atom molecules, profiles/round6_probes.txt:
+    //  4 .. 16 molecules 1.08 -> 1.11, 32 (27 row blocks) 1.29 -> 1.29, 48 (41) 1.70 -> 1.63, 64 1.72 -> 1.64, 128 2.48 -> 2.35, 256 ragged 4.18 -> 3.89)
+    const bool fused = pgather && m->node_fused != 1 && m->gemm_bf16_lds != 1 && Nl.w3_Bp16 && Nl.w4_Bp16 &&
+                       (m->node_fused == 2 || (M + 31) / 32 >= MCG_NF_MIN_ROWBLOCKS);
+    if (pl->pab_ready) {
+        pl->pab_ready = false;                                   // this layer's projections came out of the previous layer's fused launch
+    } else if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
+                            MCG_ACT_NONE, s, lp ? E.pab_Bp16 : nullptr, x6g ? E.pab_Bp16x3 : nullptr, pl, pab_rows16(M), nullptr, 2, m,
+                            blocked)) return e;
     if (int e = apply_pending_x(pl, s)) return e;              // (only if the GEMM above could not carry it)
     if (int e = run_edge(pl, E, false, pl->P, s, lp, m->x6, wgc)) return e;
+    if (fused) {
+        const EdgeLayer& Nx = (layer & 1) ? m->equiv[layer >> 1] : m->gcl_edge[layer + 1];     // whose first layer reads h' next
+        McgNodeFusedArgs a{};
+        a.h = pl->h; a.ldh = HP; a.P = pl->P; a.ldp = HP; a.a2_rows = pl->pslots4; a.a2_nsum = pl->pspan;
+        a.w3 = Nl.w3_Bp16; a.b3 = Nl.b3; a.w4 = Nl.w4_Bp16; a.b4 = Nl.b4; a.h_out = pl->h2; a.ldo = HP;
+        a.wab = Nx.pab_Bp16; a.bab = Nx.pab_bias; a.pab = pl->pab; a.ldpab = 2 * HP; a.pab_blocked = blocked ? 1 : 0; a.M = M;
+        MCG_HIP(mcg_node_fused_launch(a, s));
+        pl->pab_ready = true;
+        std::swap(pl->h, pl->h2);
+        return MCG_OK;
+    }
     const int4* gather = nullptr;
     if (wgc && f32 && !keep_agg) {
         gather = pl->units().node_slots;                        // the node GEMM adds an atom's rows of U itself
@@ -334,9 +355,11 @@ int run_equiv(const mcg_egnn* m, mcg_plan* pl, int block, hipStream_t s) {
     const EdgeLayer& E = m->equiv[block];
     const int M = pl->M;
     const bool wgc = edge_wgc(m, pl);
-    if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
-                     MCG_ACT_NONE, s, m->bf16 ? E.pab_Bp16 : nullptr, (m->x6 && m->x6_gemm) ? E.pab_Bp16x3 : nullptr, nullptr,
-                     pab_rows16(M), nullptr, 2, m, m->bf16 && pl->MT == 4 && MCG_PAB_BLOCKED)) return e;
+    if (pl->pab_ready) {
+        pl->pab_ready = false;                                   // (came out of gcl_1's fused node launch)
+    } else if (int e = gemm(pl->h, HP, H, nullptr, 0, 0, E.pab_Bp, E.pab_bias, nullptr, 0, pl->pab, 2 * HP, M, 2 * NT, 2 * HP,
+                            MCG_ACT_NONE, s, m->bf16 ? E.pab_Bp16 : nullptr, (m->x6 && m->x6_gemm) ? E.pab_Bp16x3 : nullptr, nullptr,
+                            pab_rows16(M), nullptr, 2, m, m->bf16 && pl->MT == 4 && MCG_PAB_BLOCKED)) return e;
     if (int e = run_edge(pl, E, true, pl->Px, s, m->bf16, m->x6, wgc)) return e;
     if (wgc) {
         pl->x_pending = true;          // applied by the next launch that can carry it (next block's first GEMM / k_output)
@@ -382,6 +405,7 @@ static int dynamics_launch(const mcg_egnn* m, mcg_plan* pl, const float* t, cons
         return MCG_OK;
     }
     pl->x_pending = false;
+    pl->pab_ready = false;
     if (pl->M > 0) {
         hipLaunchKernelGGL(k_prep_embed, dim3(pl->M), dim3(128), 0, s, xh, t, context, pl->node_mol, pl->node_off, pl->N,
                            m->emb_wT, m->emb_b, pl->h, pl->x, pl->x0);
@@ -496,6 +520,7 @@ int mcg_egnn_gcl_debug(const mcg_egnn* m, mcg_plan* pl, int layer, const float* 
     MCG_HIP(hipMemcpy2DAsync(pl->x, 4 * sizeof(float), x_in, 3 * sizeof(float), 3 * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));
     MCG_HIP(hipMemcpy2DAsync(pl->x0, 4 * sizeof(float), x0, 3 * sizeof(float), 3 * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));
     pl->x_pending = false;
+    pl->pab_ready = false;
     return run_gcl(m, pl, layer, s, /*keep_agg=*/true);      // (agg materialised for mcg_plan_peek)
 }
 
@@ -561,6 +586,7 @@ int mcg_egnn_block_debug(const mcg_egnn* m, mcg_plan* pl, int block, float* h_io
     MCG_HIP(hipMemcpy2DAsync(pl->x, 4 * sizeof(float), x_io, 3 * sizeof(float), 3 * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));
     MCG_HIP(hipMemcpy2DAsync(pl->x0, 4 * sizeof(float), x0, 3 * sizeof(float), 3 * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));
     pl->x_pending = false;
+    pl->pab_ready = false;
     if (int e = run_block(m, pl, block, s)) return e;
     if (int e = apply_pending_x(pl, s)) return e;
     MCG_HIP(hipMemcpy2DAsync(h_io, H * sizeof(float), pl->h, HP * sizeof(float), H * sizeof(float), pl->M, hipMemcpyDeviceToDevice, s));

@@ -94,6 +94,7 @@ struct mcg_egnn {
     bool x6_gemm = true;        // f32x6 mode: node-side GEMMs on the split-operand kernel too
     int gemm_rn = 0, gemm_x6_rn = 0;   // wave tile width of the node GEMMs (0 = the launcher's cost model)
     int gemm_bf16_lds = 0;             // MCG_OPT_GEMM_BF16_LDS: 0 auto, 1 never, 2 whenever the shape allows
+    int node_fused = 0;                // MCG_OPT_NODE_FUSED: 0 auto (from 32 row blocks on), 1 never, 2 whenever the bf16 gather path runs
     uint32_t opt_epoch = 0;     // bumped by mcg_egnn_set_precision / mcg_egnn_set_option: part of the captured graph's key,
                                 // so a plan that already captured its launches re-captures after a change
     float *emb_wT = nullptr, *emb_b = nullptr, *out_w = nullptr, *out_b = nullptr;
@@ -129,6 +130,7 @@ struct mcg_plan {
     int4* pslots4 = nullptr;
     int pspan = 0;                          // most slots any atom has; the gathers need <= 4
     bool x_pending = false;                 // host-side: a coordinate update sits in pending_u / pending_slots, not yet applied to x
+    bool pab_ready = false;                 // host-side: the next edge layer's first-layer projections are already in `pab` (fused node launch)
     const float* pending_u = nullptr;       // Ux (workgroup-level sums) or Px (per-unit partial sums)
     const int4* pending_slots = nullptr;
     std::vector<void*> allocs;              // blocks of the plan pool (mcg_dev_alloc)

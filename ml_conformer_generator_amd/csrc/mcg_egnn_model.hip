@@ -247,6 +247,7 @@ int mcg_egnn_set_option(mcg_egnn* m, int option, int value) {
         case MCG_OPT_GEMM_RN: if (value >= 0 && value <= 3) { m->gemm_rn = value; ++m->opt_epoch; return MCG_OK; } break;
         case MCG_OPT_GEMM_X6_RN: if (value >= 0 && value <= 3) { m->gemm_x6_rn = value; ++m->opt_epoch; return MCG_OK; } break;
         case MCG_OPT_GEMM_BF16_LDS: if (value >= 0 && value <= 2) { m->gemm_bf16_lds = value; ++m->opt_epoch; return MCG_OK; } break;
+        case MCG_OPT_NODE_FUSED: if (value >= 0 && value <= 2) { m->node_fused = value; ++m->opt_epoch; return MCG_OK; } break;
         default: break;
     }
     mcg_set_error("mcg_egnn_set_option: unknown option %d or value %d out of range", option, value);

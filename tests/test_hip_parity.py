@@ -2093,6 +2093,7 @@ def test_bf16_mode_gathers_partial_sums_in_the_node_gemm(edm_sd):
     for n_ranges in (1, 2):
         plan = d.plan(sizes, N, n_ranges=n_ranges)
         assert plan.edge_mt == 4
+        _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_NODE_FUSED, 1), "mcg_egnn_set_option")       # three launches per layer (round 5)
         _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_GEMM_BF16_LDS, 1), "mcg_egnn_set_option")    # the 32-row kernel
         for rn in (0, 1, 2, 3):
             _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_GEMM_RN, rn), "mcg_egnn_set_option")
@@ -2116,8 +2117,21 @@ def test_bf16_mode_gathers_partial_sums_in_the_node_gemm(edm_sd):
         assert int(c[1].sum()) == 63 * n_ranges, c
         if n_ranges == 1:
             assert int(c[1][7]) == 63, c                  # ~4 400 atoms in one range: the automatic choice is the LDS kernel
+        # round 6: the node phase of a GCL layer as ONE launch (W3 -> SiLU -> W4 -> + h -> the next edge layer's first-layer
+        # projections, mcg_node_fused.h): forced, then the automatic choice - 18 fused launches + one first-layer GEMM per block
+        # (it carries the coordinate update) instead of 63 GEMM launches, and not a bit of difference
+        for fused in (2, 0):
+            _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_NODE_FUSED, fused), "mcg_egnn_set_option")
+            launches()
+            outs.append(d.run(plan, t, z, ctx).clone())
+            c = launches()
+            if fused == 2 or n_ranges == 1:
+                assert int(c[1][6]) == 18 * n_ranges and int(c[1].sum()) == 27 * n_ranges, (fused, n_ranges, c)
+            else:
+                assert int(c[1].sum()) in (27 * n_ranges, 63 * n_ranges), c
+        _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_NODE_FUSED, 1), "mcg_egnn_set_option")
     for k, o in enumerate(outs):
-        assert torch.equal(o, outs[6 * (k // 6)]), k        # kernels and tile widths do not change a bit
+        assert torch.equal(o, outs[8 * (k // 8)]), k        # kernels, tile widths and the launch structure do not change a bit
         # (molecule ranges cut the 64-row units elsewhere: an atom's partial sums split differently - fp32 re-association
         #  that the bf16 operand rounding can amplify to a rounding flip)
         assert float((o - outs[0]).abs().max()) <= 3e-3 * float(ref32.abs().max())
@@ -2128,13 +2142,21 @@ def test_bf16_mode_gathers_partial_sums_in_the_node_gemm(edm_sd):
     M = plan.n_real_nodes
     h0 = torch.randn(M, 420, generator=g).to(DEV)
     x0 = (torch.randn(M, 3, generator=g) * 2).to(DEV)
-    for lds in (1, 2):
+    blocks = []
+    for lds, fused in ((1, 1), (2, 1), (2, 2)):
         _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_GEMM_BF16_LDS, lds), "mcg_egnn_set_option")
+        _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_NODE_FUSED, fused), "mcg_egnn_set_option")
         via_combine = d.gcl_debug(plan, 0, h0, x0, x0)["h_out"]
+        launches()
         h_blk, x_blk = d.block_debug(plan, 0, h0, x0, x0)         # gcl_0, gcl_1, coordinate layer
+        c = launches()
+        assert int(c[1][6]) == (2 if fused == 2 else 0) and int(c[1].sum()) == (3 if fused == 2 else 7), (lds, fused, c)
         via2 = d.gcl_debug(plan, 1, via_combine, x0, x0)["h_out"]
-        assert torch.equal(h_blk, via2), lds
+        assert torch.equal(h_blk, via2), (lds, fused)
+        blocks.append((h_blk.clone(), x_blk.clone()))
+    assert all(torch.equal(b[0], blocks[0][0]) and torch.equal(b[1], blocks[0][1]) for b in blocks)     # x too: the fused launch's Pab feeds the coordinate layer
     _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_GEMM_BF16_LDS, 0), "mcg_egnn_set_option")
+    _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_NODE_FUSED, 1), "mcg_egnn_set_option")
     # the LDS-staged kernel at shapes the automatic choice never gives it: a ragged last row block (M % 32 = 1, 31), fewer rows
     # than one block, a single molecule - forced on against forced off, bit for bit
     for small in ([17, 16], [31], [6, 7, 9, 11], [39] * 3 + [22]):
@@ -2152,4 +2174,14 @@ def test_bf16_mode_gathers_partial_sums_in_the_node_gemm(edm_sd):
             c = launches()
             assert (int(c[1][7]) > 0) == (lds == 2), (small, lds, c)
         assert torch.equal(res[0], res[1]), small
+        # ... and the fused node launch at the same shapes (ragged last row block, fewer rows than one block)
+        _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_GEMM_BF16_LDS, 0), "mcg_egnn_set_option")
+        _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_NODE_FUSED, 2), "mcg_egnn_set_option")
+        launches()
+        res.append(d.run(d.plan(sz, Ns), ts, zs, cs).clone())
+        c = launches()
+        assert int(c[1][6]) == 18, (small, c)
+        assert torch.equal(res[0], res[2]), small
+        _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_NODE_FUSED, 1), "mcg_egnn_set_option")
     _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_GEMM_BF16_LDS, 0), "mcg_egnn_set_option")
+    _lib.check(L.mcg_egnn_set_option(d.handle, _lib.OPT_NODE_FUSED, 0), "mcg_egnn_set_option")

@@ -19,6 +19,7 @@ ap.add_argument("--ranges", type=int, default=0, help="mcg_plan_opts.n_ranges (0
 ap.add_argument("--latency-mode", type=int, default=-1, help="mcg_plan_set_latency_mode: -1 auto, 0 four-tile units only, 1 k_edge_ns")
 ap.add_argument("--gemm-rn", type=int, default=0, help="mcg_egnn_set_option(MCG_OPT_GEMM_RN): wave tile width of the 32-row GEMM kernels")
 ap.add_argument("--bf16-lds", type=int, default=0, help="mcg_egnn_set_option(MCG_OPT_GEMM_BF16_LDS): 0 auto, 1 the 32-row kernel, 2 the LDS-staged kernel")
+ap.add_argument("--node-fused", type=int, default=0, help="mcg_egnn_set_option(MCG_OPT_NODE_FUSED): 0 auto, 1 three launches per layer, 2 one fused launch")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 dyn = EGNNDynamics(device=dev)
@@ -28,6 +29,8 @@ if a.gemm_rn:
     dyn.set_option(_lib.OPT_GEMM_RN, a.gemm_rn)
 if a.bf16_lds:
     dyn.set_option(_lib.OPT_GEMM_BF16_LDS, a.bf16_lds)
+if a.node_fused:
+    dyn.set_option(_lib.OPT_NODE_FUSED, a.node_fused)
 if a.mols > 0:
     sizes = torch.full((a.mols,), a.atoms, dtype=torch.int32); N = a.atoms
 elif a.shape == "c2":
