@@ -194,8 +194,12 @@ static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, c
     // aggregation) the same shape runs 4.36 / 4.08 / 5.02, and 27-atom batches of 96 / 128 / 160 / 192 molecules 2.25 / 2.26,
     // 2.54 / 2.73, 2.98 / 3.16, 3.51 / 3.30 with 1 / 2 ranges (tools/ab_bf16_ranges.sh): two ranges pay exactly when each
     // half still has the 80 row blocks of 32 atoms from which the bf16 node GEMMs take the LDS-staged kernel
-    // (MCG_LDSG_MIN_ROWBLOCKS, mcg_gemm.h) - 5 120 atoms in all.
-    constexpr int BF16_TWO_RANGES_FROM_ATOMS = 2 * 80 * 32;
+    // (MCG_LDSG_MIN_ROWBLOCKS, mcg_gemm.h) - 5 120 atoms in all.  Round 6, with the node phase of a layer as one fused launch from
+    // 32 row blocks on (mcg_node_fused.h): 27-atom batches of 48 / 64 / 80 / 96 / 112 / 128 / 256 / 320 molecules 1.62 / 1.60, 1.64 / 1.80,
+    // 1.88 / 1.70, 2.13 / 1.94, 2.15 / 2.11, 2.38 / 2.20, 3.78 / 3.66 (3: 3.82), 5.05 / 4.43 (3: 4.47) ms with 1 / 2 ranges, the 256-ragged
+    // shape 4.16 / 3.93 / 4.12: the same law one level down - two ranges pay when each half keeps the 32 row blocks from which the
+    // fused launch runs (2 048 atoms in all); three never do up to 8 640 atoms.
+    constexpr int BF16_TWO_RANGES_FROM_ATOMS = 2 * 32 * 32;
     int parts = 1;
     if (n_ranges > 0) parts = n_ranges;
     else if (p->MT == 1) parts = p->n_mtiles < 3600 ? 1 : p->n_mtiles < 5200 ? 2 : p->n_mtiles < 14000 ? 3 : 4;
