@@ -671,6 +671,21 @@ def spawn_ranks(n):
     sys.exit(0)
 
 
+def pin_this_rank(world, local_rank):
+    """Placement (round 6): a rank - its torch threads and, by inheritance, its host-pool worker processes - is pinned to the cores
+    of its GPU's NUMA node, shared between the ranks of that node (ml_conformer_generator_amd/affinity.py: sysfs only, no HIP call;
+    loaded BY PATH - the package's __init__ would load the HIP library first).  On by default for N > 1, off for a lone rank;
+    MCG_BENCH_AFFINITY=0 / 1 overrides.  Returns the cores now in force (None = not pinned)."""
+    if os.environ.get("MCG_BENCH_AFFINITY", "1" if world > 1 else "0") == "0":
+        return None
+    import importlib.util as _ilu
+    spec = _ilu.spec_from_file_location("_mcg_affinity", os.path.join(REPO, "ml_conformer_generator_amd", "affinity.py"))
+    aff = _ilu.module_from_spec(spec)
+    spec.loader.exec_module(aff)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    return aff.pin(aff.rank_cpus(local_rank, local_world)) or None
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -685,17 +700,7 @@ def main():
     # N rank processes share one host: without a cap each keeps torch's default intra-op pool of EVERY core (256 threads per
     # rank on the GPU box; the CPU thread sweep below shows what oversubscription costs).  The hot path needs the host for
     # launches, the size draw and the record assembly only.
-    # Placement (round 6): each rank - its torch threads and, by inheritance, its host-pool worker processes - is pinned to the
-    # cores of its GPU's NUMA node, shared between the ranks of that node (ml_conformer_generator_amd/affinity.py: sysfs only,
-    # no HIP call; MCG_BENCH_AFFINITY=0 leaves the process alone).  A lone rank is left alone by default.
-    rank_cpus = None
-    if os.environ.get("MCG_BENCH_AFFINITY", "1" if world > 1 else "0") != "0":
-        import importlib.util as _ilu
-        _spec = _ilu.spec_from_file_location("_mcg_affinity", os.path.join(REPO, "ml_conformer_generator_amd", "affinity.py"))
-        _aff = _ilu.module_from_spec(_spec)
-        _spec.loader.exec_module(_aff)               # by path: the package's __init__ would load the HIP library first
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-        rank_cpus = _aff.pin(_aff.rank_cpus(local_rank, local_world))
+    rank_cpus = pin_this_rank(world, local_rank)
     n_cores = len(rank_cpus) if rank_cpus else (os.cpu_count() or 1) // max(1, world)
     host_threads = max(1, min(16, n_cores))
     torch.set_num_threads(host_threads)

@@ -280,13 +280,13 @@ __global__ __launch_bounds__(MCG_LDSG_THREADS) void mcg_node_fused_bf16_kernel(M
     }
 }
 
+// (only the two-row gather is instantiated: an atom of <= 42 atoms' molecule owns <= 41 edge rows, i.e. at most two 64-row units;
+//  plans whose atoms span more take the three-launch path - run_gcl)
 static inline hipError_t mcg_node_fused_launch(const McgNodeFusedArgs& a, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
+    if (!a.a2_rows || a.a2_nsum > 2) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((a.M + 31) / 32));
-    const int gather = a.a2_rows ? (a.a2_nsum > 2 ? 4 : 2) : 0;
     mcg_count_gemm_launch(1, 6);                 // family 1 (bf16), slot 6 = the fused node kernel (W3 + W4 + next first layer)
-    if (gather == 4) hipLaunchKernelGGL((mcg_node_fused_bf16_kernel<4>), grid, dim3(MCG_LDSG_THREADS), 0, s, a);
-    else if (gather == 2) hipLaunchKernelGGL((mcg_node_fused_bf16_kernel<2>), grid, dim3(MCG_LDSG_THREADS), 0, s, a);
-    else hipLaunchKernelGGL((mcg_node_fused_bf16_kernel<0>), grid, dim3(MCG_LDSG_THREADS), 0, s, a);
+    hipLaunchKernelGGL((mcg_node_fused_bf16_kernel<2>), grid, dim3(MCG_LDSG_THREADS), 0, s, a);
     return hipGetLastError();
 }

@@ -386,3 +386,24 @@ def test_bench_counts_gpus_without_touching_hip_and_ends_all_ranks_when_one_fail
     assert '"n_gpus"' not in r.stdout
     assert "child ranks exited" in r.stderr
     assert time.time() - t0 < 300
+
+
+def test_bench_ranks_pin_themselves_without_loading_the_hip_library():
+    """Round 6: `bench.py` ranks pin themselves to a share of the host's cores before they touch the GPU - through `affinity.py`
+    loaded by path (no package import, no HIP library), on by default only for N > 1.  Run in a child: it narrows its own mask."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, REPO_DIR); import bench\n"
+            "a = sorted(os.sched_getaffinity(0))\n"
+            "lone = bench.pin_this_rank(1, 0)\n"
+            "r0 = bench.pin_this_rank(2, 0); now0 = sorted(os.sched_getaffinity(0))\n"
+            "os.sched_setaffinity(0, a)\n"
+            "r1 = bench.pin_this_rank(2, 1)\n"
+            "print(lone is None, r0 == now0, len(a) < 2 or (len(r0) == len(a) // 2 + len(a) % 2 and not set(r0) & set(r1)), "
+            "'ml_conformer_generator_amd' not in sys.modules)\n").replace("REPO_DIR", repr(repo))
+    env = dict(os.environ)
+    env.pop("MCG_BENCH_AFFINITY", None)
+    env.pop("LOCAL_WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert out.stdout.split() == ["True", "True", "True", "True"], out.stdout + out.stderr
