@@ -14,10 +14,11 @@ TRAJ_REL = 1e-3
 # Judged-length trajectories (T = 100 forward, T = 250 inpainting with resampling; tests/golden/e2e_T100_b2n27.npz,
 # inpaint_T250_rs1_b2.npz).  Those fixtures use the CONTRACTIVE weight recipe (a trajectory of 100+ levels under the full-gain
 # recipes amplifies one ulp to per cent in the reference itself and can pin nothing), and a contractive network also damps what a
-# knocked-out term changes: under TRAJ_REL the mutation check saw most GCL mutations at only 1-3 x the tolerance
-# (profiles/round6_parity_sensitivity.txt).  The fp32 paths follow these trajectories to 7e-7 (HIP) / 1e-6 (oracle) of the step's
-# magnitude, so their replays are held to LONG_TRAJ_REL instead - 100 x tighter, 14 x the measured deviation.
-LONG_TRAJ_REL = 1e-5
+# knocked-out term changes: under TRAJ_REL the mutation check saw most GCL mutations at only 1-3 x the tolerance and the first
+# block's first aggregate at 0.05-0.1 x (profiles/round6_parity_sensitivity.txt).  The fp32 paths follow these trajectories to
+# 7.4e-7 (HIP) / 7.6e-7 (oracle) of the step's magnitude, so their replays are held to LONG_TRAJ_REL instead - 250 x tighter, 5 x the
+# measured deviation, and the least visible required mutation then sits at >= 12 x the tolerance.
+LONG_TRAJ_REL = 4e-6
 
 
 def _groups(last_dim, split):
