@@ -260,40 +260,41 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
     bf16x8* const a_lds = reinterpret_cast<bf16x8*>(wdl + 2 * W64_KP);   // [2][SPLIT][4][64]
     float* const xchg = wdl + 2 * W64_KP + SPLIT * W64_A_FLOATS;         // [4 waves][64 rows]
     float* const ri = xchg + 4 * 64;                                     // [64 rows][4]: seg, ux, uy, uz
-    for (int i = threadIdx.x; i < HP; i += 256) { par[i] = p.b2[i]; par[HP + i] = p.wv[i]; }
-    for (int i = threadIdx.x; i < W64_KP; i += 256) { wdl[i] = p.wd[i]; wdl[W64_KP + i] = p.wd0[i]; }
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
     const int unit = mcg_xcd_remap(blockIdx.x, gridDim.x);               // 64-row unit == "wave" of the MT = 4 plan
 
-    // rows of MY row tile (tile wid of the unit): A-operand generation + row facts for everybody's epilogue
+    // ---- prologue, TWO memory round trips (round 6).  Until round 5 this was a chain of SEVEN dependent ones - two strided loops
+    //      staging b2 | wv and wd | wd0 into LDS (each iteration: load, wait, ds_write), the row's (i, j) as two dependent 4-byte
+    //      loads, then the coordinates, and only then the first operand loads - at the head of every one of the launch's 3 005
+    //      workgroups: 15 us of a 139 us launch (ablation without the staging alone: profiles/round6_probes.txt section 5).
+    //      Round trip 1: the row word (ONE 8-byte load: as an int2 whose .y is only used when .x >= 0 hipcc emits two dependent
+    //      loads) and the eight parameter values of this thread, unrolled, into registers.  Round trip 2: coordinates, layer-1
+    //      inputs of blocks 0 and 1, the two weight stages - all issued back to back; the parameters go to LDS under their shadow.
     int vi = 0, vj = 0, sg = -1;
     float d2, d02, ux = 0.f, uy = 0.f, uz = 0.f;
+    const int tile = unit * 4 + wid;
+    long long rawij = -1;
+    if (tile < p.n_mtiles) rawij = reinterpret_cast<const long long*>(p.row_ij)[tile * 16 + c];
+    float stg[8];
+#ifndef MCG_ABL_NOPARAM      // (ablation switch: parameters never staged - wrong results)
     {
-        const int tile = unit * 4 + wid;
-        const int r = tile * 16 + c;
-        if (tile < p.n_mtiles) {
-            const int2 ij = p.row_ij[r];
-            if (ij.x >= 0) { vi = ij.x; vj = ij.y & 0xffffff; sg = ij.y >> 24; }
-        }
-        const f32x4 xi = *reinterpret_cast<const f32x4*>(p.x + (size_t)vi * 4);
-        const f32x4 xj = *reinterpret_cast<const f32x4*>(p.x + (size_t)vj * 4);
-        const f32x4 yi = *reinterpret_cast<const f32x4*>(p.x0 + (size_t)vi * 4);
-        const f32x4 yj = *reinterpret_cast<const f32x4*>(p.x0 + (size_t)vj * 4);
-        const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
-        const float ex = yi[0] - yj[0], ey = yi[1] - yj[1], ez = yi[2] - yj[2];
-        d2 = dx * dx + dy * dy + dz * dz;
-        d02 = ex * ex + ey * ey + ez * ez;
-        if (EQUIV) {
-            const float inv = 1.0f / sqrtf(d2 + 1e-8f);
-            ux = dx * inv; uy = dy * inv; uz = dz * inv;
-        }
-        if (g == 0) {
-            float* dst = ri + (16 * wid + c) * 4;
-            dst[0] = __int_as_float(sg); dst[1] = ux; dst[2] = uy; dst[3] = uz;
-        }
+        const int t0 = threadIdx.x, t1 = threadIdx.x + 256;
+        const int h1 = t1 < HP ? t1 : HP - 1, k1 = t1 < W64_KP ? t1 : W64_KP - 1;
+        stg[0] = p.b2[t0]; stg[1] = p.wv[t0]; stg[2] = p.b2[h1]; stg[3] = p.wv[h1];
+        stg[4] = p.wd[t0]; stg[5] = p.wd0[t0]; stg[6] = p.wd[k1]; stg[7] = p.wd0[k1];
     }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const int ix = (int)rawij, iy = (int)(rawij >> 32);
+        if (ix >= 0) { vi = ix; vj = iy & 0xffffff; sg = iy >> 24; }
+    }
+    const f32x4 xi = *reinterpret_cast<const f32x4*>(p.x + (size_t)vi * 4);
+    const f32x4 xj = *reinterpret_cast<const f32x4*>(p.x + (size_t)vj * 4);
+    const f32x4 yi = *reinterpret_cast<const f32x4*>(p.x0 + (size_t)vi * 4);
+    const f32x4 yj = *reinterpret_cast<const f32x4*>(p.x0 + (size_t)vj * 4);
     // Operand addresses are (buffer descriptor in SGPRs) + (one 32-bit lane offset) + (scalar block offset): as
     // 64-bit per-lane pointers hipcc keeps ~20 VGPRs of addresses alive and the f32x6 variant spills.
     // BLK (bf16 mode, round 5): the layer-1 inputs come in the BLOCKED layout Pab[part][k-block][piece][atom][4] the bf16
@@ -473,21 +474,39 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
     // weight refills issued ~0.7 blocks earlier although the inputs themselves were requested 1.5 blocks ahead.  Requested
     // FIRST, with the 14 weight loads behind them, every path allows the 15 newer loads of the steady state.
     f32x4 v_first[4];
-    if constexpr (SPLIT == 1) {
-        load_a(0, v_first);
-        load_a(1, vset[SPLIT == 1 ? 1 : 0]);      // block 1 -> set 1 (consumed in the middle of block 0)
-        __builtin_amdgcn_sched_barrier(0);        // (pinned: left alone the scheduler sinks these behind the weight loads again)
-    }
+    load_a(0, v_first);
+    if constexpr (SPLIT == 1) load_a(1, vset[SPLIT == 1 ? 1 : 0]);      // block 1 -> set 1 (consumed in the middle of block 0)
+    __builtin_amdgcn_sched_barrier(0);            // (pinned: left alone the scheduler sinks these behind the weight loads again)
     load_b(Bq[0], 0);
     load_b(Bq[1], 1);
-    __syncthreads();                              // wd | wd0 staged
-    if constexpr (SPLIT == 1) {
-        agen_store(v_first, 0, 0);
-    } else {
-        f32x4 v[4];
-        load_a(0, v);
-        agen_store(v, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // (everything of round trip 2 is in flight; now the work that only needs round trip 1 and the coordinates)
+#ifndef MCG_ABL_NOPARAM
+    {
+        const int t0 = threadIdx.x, t1 = threadIdx.x + 256;
+        par[t0] = stg[0]; par[HP + t0] = stg[1];
+        if (t1 < HP) { par[t1] = stg[2]; par[HP + t1] = stg[3]; }
+        wdl[t0] = stg[4]; wdl[W64_KP + t0] = stg[5];
+        if (t1 < W64_KP) { wdl[t1] = stg[6]; wdl[W64_KP + t1] = stg[7]; }
     }
+#endif
+    {
+        const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
+        const float ex = yi[0] - yj[0], ey = yi[1] - yj[1], ez = yi[2] - yj[2];
+        d2 = dx * dx + dy * dy + dz * dz;
+        d02 = ex * ex + ey * ey + ez * ez;
+        if (EQUIV) {
+            const float inv = 1.0f / sqrtf(d2 + 1e-8f);
+            ux = dx * inv; uy = dy * inv; uz = dz * inv;
+        }
+        if (g == 0) {
+            float* dst = ri + (16 * wid + c) * 4;
+            dst[0] = __int_as_float(sg); dst[1] = ux; dst[2] = uy; dst[3] = uz;
+        }
+    }
+    // (not __syncthreads(): hipcc drains the vector-memory counter in front of it - the operand loads above are meant to stay in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // b2 | wv | wd | wd0 staged, row facts published
+    agen_store(v_first, 0, 0);
 #pragma unroll 1
     for (int kb = 0; kb < KB16; kb += 2) {        // KB16 = 14 is even
         block(kb, 0, std::integral_constant<int, 0>{});

@@ -469,7 +469,15 @@ static int dynamics_entry(const mcg_egnn* m, mcg_plan* pl, const float* t, const
         }
         (void)hipGetLastError();
     }
-    if (pl->graph_exec) { (void)hipGraphExecDestroy(pl->graph_exec); pl->graph_exec = nullptr; }
+    if (pl->graph_exec) {
+        // the old graph may still be RUNNING (every call is asynchronous; a caller that changes an option or moves its tensors
+        // re-captures right behind a launch).  Destroying an executable graph in flight is legal by the API's letter, but one
+        // intermittent host-side segfault inside this function was seen on ROCm 7.2 in a test that toggles options between
+        // back-to-back calls of a two-range plan (round 6): wait for the plan's own last launch first - re-captures are rare
+        if (pl->ev_done && pl->ev_pending && hipEventSynchronize(pl->ev_done) != hipSuccess) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }
+        (void)hipGraphExecDestroy(pl->graph_exec);
+        pl->graph_exec = nullptr;
+    }
     hipGraph_t graph = nullptr;
     if (hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();

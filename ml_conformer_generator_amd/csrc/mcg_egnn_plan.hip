@@ -76,7 +76,9 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, const m
     void* tab_block = nullptr;
     if (int e = mcg_dev_alloc(tab_bytes, &tab_block)) { delete p; return e; }
     p->allocs.push_back(tab_block);
-    if (hipMemcpy(tab_block, stage.data(), tab_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+    // (on the setup stream, not the legacy stream: mcg_devmem.hip - plan creation must work while another thread captures a graph)
+    hipStream_t ss = mcg_setup_stream();
+    if (hipMemcpyAsync(tab_block, stage.data(), tab_bytes, hipMemcpyHostToDevice, ss) != hipSuccess || hipStreamSynchronize(ss) != hipSuccess) {
         (void)hipGetLastError();
         mcg_set_error("mcg_plan_create: table upload failed");
         mcg_plan_destroy(p);
@@ -104,7 +106,7 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, const m
     if (int e = mcg_dev_alloc(ws_bytes, &ws_block)) { mcg_plan_destroy(p); return e; }
     p->allocs.push_back(ws_block);
     // (the plan's own streams are non-blocking, i.e. they do not order with stream 0: wait for the memset here)
-    if (hipMemset(ws_block, 0, ws_bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+    if (hipMemsetAsync(ws_block, 0, ws_bytes, ss) != hipSuccess || hipStreamSynchronize(ss) != hipSuccess) {
         (void)hipGetLastError();
         mcg_set_error("mcg_plan_create: workspace memset failed");
         mcg_plan_destroy(p);
