@@ -299,18 +299,21 @@ def test_prestart_spawns_the_workers_in_the_background_and_submit_waits_for_it()
         t0 = time.perf_counter()
         p.prestart([ref("square_chunk")])              # + the task file: the workers import it (numpy) as they come up
         p.prestart()                                   # idempotent while the start is in progress
-        assert time.perf_counter() - t0 < 0.05 and HP.SerialExecutor().prestart() is None
+        assert time.perf_counter() - t0 < 0.5 and HP.SerialExecutor().prestart() is None       # (returns at once: spawning 4 interpreters takes longer)
         assert p.submit(ref("square_chunk"), [5]).result(timeout=60) == [25]       # an early submit waits for the start
         assert len(p.worker_pids()) == 4 and p.last_start_ms is not None
         time.sleep(0.05)
         t0 = time.perf_counter()
         p.prestart()                                   # already running: nothing to do
-        assert time.perf_counter() - t0 < 0.01 and len(p.worker_pids()) == 4
+        assert time.perf_counter() - t0 < 0.25 and len(p.worker_pids()) == 4
         # what is left on the critical path once the workers are up and hold the task file: one round trip per worker
         time.sleep(1.0)
         t0 = time.perf_counter()
         got = [f.result(timeout=60) for f in [p.submit(ref("sleep_chunk"), [k], (0.005,)) for k in range(4)]]
-        assert (time.perf_counter() - t0) * 1e3 < 20.0 and len({pid for ((_, pid),) in got}) == 4
+        took_ms = (time.perf_counter() - t0) * 1e3
+        assert len({pid for ((_, pid),) in got}) == 4
+        # (20 ms on an idle host; the bound leaves room for a contended one - a cold worker would add its interpreter start + numpy import)
+        assert took_ms < 150.0, took_ms
     finally:
         p.close()
 
