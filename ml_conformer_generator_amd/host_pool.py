@@ -100,14 +100,21 @@ SAMPLES_TASK = TaskRef(RDKIT_TASKS, "samples_chunk")
 
 def default_workers() -> int:
     """`n_host_workers` default: min(32, this rank's share of the host cores) - MMFF is tens of ms per molecule, a generate
-    call has 10..2 048.  Under a one-process-per-GPU launcher (`LOCAL_WORLD_SIZE`, set by torch.distributed.run) the cores
-    are divided between the ranks of the node, like the intra-op thread cap of bench.py."""
-    cores = os.cpu_count() or 1
+    call has 10..2 048.  A process that is already RESTRICTED to a subset of the cores (pinned by `affinity.pin`, a launcher, a
+    cgroup cpuset) takes that subset as its share; otherwise, under a one-process-per-GPU launcher (`LOCAL_WORLD_SIZE`, set
+    by torch.distributed.run), the cores are divided between the ranks of the node, like the intra-op thread cap of bench.py."""
+    total = os.cpu_count() or 1
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = total
+    if 0 < allowed < total:
+        return max(1, min(32, allowed))
     try:
         local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
     except ValueError:
         local = 1
-    return max(1, min(32, cores // local))
+    return max(1, min(32, total // local))
 
 
 def chunk_bounds(n: int, size: int) -> List[Tuple[int, int]]:

@@ -119,6 +119,17 @@ def test_shared_pool_and_chunking_rules():
     assert HP.task_chunk(5, 0) == 5 and HP.task_chunk(0, 4) == 1
     with pytest.raises(ValueError):
         HP.HostPool(0)
+    # a process already restricted to a subset of the cores (pinned rank, cpuset) takes THAT as its share - no second division
+    if hasattr(os, "sched_setaffinity") and len(os.sched_getaffinity(0)) >= 2 and len(os.sched_getaffinity(0)) == os.cpu_count():
+        import subprocess
+        import sys
+        code = ("import os, importlib.util\n"
+                "spec = importlib.util.spec_from_file_location('hp', %r); hp = importlib.util.module_from_spec(spec); spec.loader.exec_module(hp)\n"
+                "os.environ['LOCAL_WORLD_SIZE'] = '8'\n"
+                "a = sorted(os.sched_getaffinity(0)); os.sched_setaffinity(0, a[:2])\n"
+                "print(hp.default_workers())\n") % HP.__file__
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+        assert out.stdout.strip() == "2", out.stdout + out.stderr
 
 
 # ------------------------------------------------------------------------------------------------ the two stages
