@@ -260,7 +260,10 @@ int gemm(const float* A1, int lda1, int K1, const float* A2, int lda2, int K2, c
             if (cand < rows16 && rt * ((n_tiles + cand - 1) / cand) <= mcg_simd_count()) { rn = cand; break; }
         // 16-row wave tiles while they fit one wave per SIMD (972 waves at config 2), 32-row ones beyond
         const long w16 = rt * ((n_tiles + rn - 1) / rn);
-        MCG_HIP(mcg_gemm16_launch(g, rn, s, w16 <= 1280 ? 1 : 2));
+#ifndef MCG_G16_DEEP
+#define MCG_G16_DEEP 1          // (measurement switch: 0 = the 3-deep operand ring for small batches too)
+#endif
+        MCG_HIP(mcg_gemm16_launch(g, rn, s, w16 <= 1280 ? 1 : 2, MCG_G16_DEEP && rn < rows16 && rn <= 2));
         return MCG_OK;
     }
     if (Bp16x3) {            // f32x6: three-part operands on the bf16 pipe, fp32-accurate

@@ -1068,9 +1068,18 @@ __global__ __launch_bounds__(256) void mcg_gemm16_kernel(McgGemmArgs p) {
     }
 }
 
+#ifndef MCG_G16_DEEP1
+#define MCG_G16_DEEP1 8
+#endif
+#ifndef MCG_G16_DEEP2
+#define MCG_G16_DEEP2 6
+#endif
 // launcher: rn in {1, 2, 3, 6} column tiles and mr in {1, 2} row tiles of 16 per wave; the optional side job adds
 // ceil(side_M * 4 / 256) workgroups.
-static inline hipError_t mcg_gemm16_launch(McgGemmArgs a, int rn, hipStream_t s, int mr = 1) {
+// `deep` (small batches, rn = 1 or 2, mr = 1): an operand ring of 8 / 6 k-groups instead of 3.  With fewer waves than SIMDs a
+// launch is ONE latency-bound chain per wave - a k-group is 4 x RN MFMAs (53 ns at RN = 1) against an L2 round trip of ~0.6 us
+// shared by the groups in flight: three in flight cost ~200 ns per group, eight ~75.  Same k order: bit-identical results.
+static inline hipError_t mcg_gemm16_launch(McgGemmArgs a, int rn, hipStream_t s, int mr = 1, bool deep = false) {
     if (a.M <= 0) return hipSuccess;
     // the EFFECTIVE tile shape - the one an instantiation exists for - sizes the grid: a width the kernel was not built
     // with would leave the kernel's wave_cols and the grid disagreeing (output columns silently unwritten)
@@ -1086,11 +1095,16 @@ static inline hipError_t mcg_gemm16_launch(McgGemmArgs a, int rn, hipStream_t s,
                                else if (gather == 3) hipLaunchKernelGGL((mcg_gemm16_kernel<RN_, 3, MR_>), grid, dim3(256), 0, s, a); \
                                else if (gather == 2) hipLaunchKernelGGL((mcg_gemm16_kernel<RN_, 2, MR_>), grid, dim3(256), 0, s, a); \
                                else hipLaunchKernelGGL((mcg_gemm16_kernel<RN_, 0, MR_>), grid, dim3(256), 0, s, a); } while (0)
+#define MCG_G16D(RN_, RING_) do { if (gather == 4) hipLaunchKernelGGL((mcg_gemm16_kernel<RN_, 4, 1, RING_>), grid, dim3(256), 0, s, a); \
+                                  else if (gather == 3) hipLaunchKernelGGL((mcg_gemm16_kernel<RN_, 3, 1, RING_>), grid, dim3(256), 0, s, a); \
+                                  else if (gather == 2) hipLaunchKernelGGL((mcg_gemm16_kernel<RN_, 2, 1, RING_>), grid, dim3(256), 0, s, a); \
+                                  else hipLaunchKernelGGL((mcg_gemm16_kernel<RN_, 0, 1, RING_>), grid, dim3(256), 0, s, a); } while (0)
     if (mr == 2) { if (rn == 3) MCG_G16(3, 2); else MCG_G16(2, 2); }
     else if (rn == 6) MCG_G16(6, 1);
     else if (rn == 3) MCG_G16(3, 1);
-    else if (rn == 1) MCG_G16(1, 1);
-    else MCG_G16(2, 1);
+    else if (rn == 1) { if (deep) MCG_G16D(1, MCG_G16_DEEP1); else MCG_G16(1, 1); }
+    else { if (deep) MCG_G16D(2, MCG_G16_DEEP2); else MCG_G16(2, 1); }
+#undef MCG_G16D
 #undef MCG_G16
     return hipGetLastError();
 }
