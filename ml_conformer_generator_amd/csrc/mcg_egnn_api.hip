@@ -473,13 +473,20 @@ static int dynamics_entry(const mcg_egnn* m, mcg_plan* pl, const float* t, const
         (void)hipGetLastError();
     }
     if (pl->graph_exec) {
-        // the old graph may still be RUNNING (every call is asynchronous; a caller that changes an option or moves its tensors
-        // re-captures right behind a launch).  Destroying an executable graph in flight is legal by the API's letter, but one
-        // intermittent host-side segfault inside this function was seen on ROCm 7.2 in a test that toggles options between
-        // back-to-back calls of a two-range plan (round 6): wait for the plan's own last launch first - re-captures are rare
-        if (pl->ev_done && pl->ev_pending && hipEventSynchronize(pl->ev_done) != hipSuccess) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }
-        (void)hipGraphExecDestroy(pl->graph_exec);
+        // A caller that changes an option or moves its tensors re-captures right behind a launch.  The old executable is NOT
+        // destroyed here: it is retired and destroyed with the plan (mcg_plan_destroy, behind the plan's completion event).
+        // Destroying an executable graph and instantiating its successor back to back is legal by the API's letter, but a test
+        // that re-captures ~20 times per plan (options toggled between back-to-back calls of a two-range plan) died inside the
+        // HIP runtime once in 8..60 runs on ROCm 7.2 (a host-side segfault in this function, a silent abort at the next
+        // synchronisation) - with and without waiting for the old graph's last launch first.  Re-captures are rare and an
+        // executable is a few hundred KB of host memory; the oldest go once 16 have piled up (after a wait for the plan's work).
+        pl->retired_graphs.push_back(pl->graph_exec);
         pl->graph_exec = nullptr;
+        if (pl->retired_graphs.size() > 16) {
+            if (pl->ev_done && pl->ev_pending && hipEventSynchronize(pl->ev_done) != hipSuccess) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }
+            for (size_t k = 0; k + 8 < pl->retired_graphs.size(); ++k) (void)hipGraphExecDestroy(pl->retired_graphs[k]);
+            pl->retired_graphs.erase(pl->retired_graphs.begin(), pl->retired_graphs.end() - 8);
+        }
     }
     hipGraph_t graph = nullptr;
     if (hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {

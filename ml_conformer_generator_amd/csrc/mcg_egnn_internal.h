@@ -154,6 +154,7 @@ struct mcg_plan {
     float* t_buf = nullptr;                 // fixed device copy of t[B] read by the captured graph
     hipStream_t cap_stream = nullptr;       // capture happens here (the caller's stream may be the null stream)
     hipGraphExec_t graph_exec = nullptr;
+    std::vector<hipGraphExec_t> retired_graphs;     // executables replaced by a re-capture: destroyed with the plan (mcg_egnn_api.hip)
     const void* g_key[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // xh, context, out, model uid, precision mode | option epoch << 8
     int graph_failed = 0;
     // Callers whose tensors move between calls (the reference's own sampler loop allocates a fresh xh / out

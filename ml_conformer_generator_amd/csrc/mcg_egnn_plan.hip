@@ -138,6 +138,7 @@ void mcg_plan_destroy(mcg_plan* p) {
         for (hipStream_t st : p->streams) (void)hipStreamSynchronize(st);       // joined behind ev_done already: returns at once
     }
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+    for (hipGraphExec_t ge : p->retired_graphs) (void)hipGraphExecDestroy(ge);
     if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     for (mcg_plan* q : p->subs) mcg_plan_destroy(q);
     for (hipStream_t st : p->streams) (void)hipStreamDestroy(st);
