@@ -332,15 +332,24 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
     const unsigned ov = (unsigned)(wid * 64 + lane) * 16u;
     const unsigned ov6 = (unsigned)((wid + 24 < NT ? wid + 24 : NT - 1) * 64 + lane) * 16u;
     bf16x8 Bq[2][NS_T];
+#ifndef MCG_W64_B_AUX
+#define MCG_W64_B_AUX 0          // (measurement switch: cache-policy bits of the weight-fragment loads - 1 sc0, 2 nt, 16 sc1)
+#endif
+#ifndef MCG_W64_A_AUX
+#define MCG_W64_A_AUX 0          // (same for the layer-1 input loads)
+#endif
     auto ld16 = [](const __amdgpu_buffer_rsrc_t& r, unsigned voff, int soff) {
-        return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, MCG_W64_A_AUX);
+    };
+    auto ld16w = [](const __amdgpu_buffer_rsrc_t& r, unsigned voff, int soff) {
+        return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, MCG_W64_B_AUX);
     };
     auto load_b = [&](bf16x8 (&dst)[NS_T], int stage) {
         stage = stage < NSTAGE ? stage : NSTAGE - 1;
         const int base = stage * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < NS_T - 1; ++i) dst[i] = __builtin_bit_cast(bf16x8, ld16(rs_b, ov, base + i * 4 * 64 * 16));
-        dst[NS_T - 1] = __builtin_bit_cast(bf16x8, ld16(rs_b, ov6, base));
+        for (int i = 0; i < NS_T - 1; ++i) dst[i] = __builtin_bit_cast(bf16x8, ld16w(rs_b, ov, base + i * 4 * 64 * 16));
+        dst[NS_T - 1] = __builtin_bit_cast(bf16x8, ld16w(rs_b, ov6, base));
     };
     auto load_a = [&](int kb, f32x4 (&v)[4]) {
         kb = kb < KB16 ? kb : KB16 - 1;
@@ -413,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bf16_w64(EdgeArgs p) {
             for (int mt = 0; mt < 4; ++mt) acc[mt][i] = mcg_mfma_bf16(af[mt], Bc[i], acc[mt][i]);
             __builtin_amdgcn_sched_barrier(0);
 #ifndef MCG_ABL_NOB          // (ablation switch: no weight refills - wrong results, an upper bound for any better weight delivery)
-            Bc[i] = __builtin_bit_cast(bf16x8, i < NS_T - 1 ? ld16(rs_b, ov, base + i * 4 * 64 * 16) : ld16(rs_b, ov6, base));
+            Bc[i] = __builtin_bit_cast(bf16x8, i < NS_T - 1 ? ld16w(rs_b, ov, base + i * 4 * 64 * 16) : ld16w(rs_b, ov6, base));
 #endif
             __builtin_amdgcn_sched_barrier(0);
             if (i == MCG_W64_AGEN_POS) mid();          // (position 0 / 1 / 3 / 5 measured: no difference)
