@@ -45,7 +45,13 @@ __global__ __launch_bounds__(MCG_LDSG_THREADS) void mcg_node_fused_bf16_kernel(M
     __shared__ bf16x8 sA[2 * MCG_NF_B1 * 2 * 64];                       // [28 k-blocks][2 row tiles][64 lanes] x 16 B = 56 KiB
     bf16x8* const sH = sA;                                              // blocks 0..13: h, later SiLU(hidden)
     bf16x8* const sG = sA + MCG_NF_B1 * 2 * 64;                         // blocks 14..27: agg, later h'
-    constexpr int RN = MCG_LDSG_RN, RING = 3, B1 = MCG_NF_B1, NTL = 27;
+#ifndef MCG_NF_RING
+#define MCG_NF_RING 3
+#endif
+#ifndef MCG_NF_OVERLAP2
+#define MCG_NF_OVERLAP2 1
+#endif
+    constexpr int RN = MCG_LDSG_RN, RING = MCG_NF_RING, B1 = MCG_NF_B1, NTL = 27;
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(MCG_LDSG_THREADS) void mcg_node_fused_bf16_kernel(M
             park_quarter(sA, B1 + kb, i, v, 32 * kb + 4 * piece);
         }
     };
-    constexpr bool OVERLAP2 = GATHER <= 2;
+    constexpr bool OVERLAP2 = GATHER <= 2 && MCG_NF_OVERLAP2;
     if constexpr (OVERLAP2) {
 #pragma unroll
         for (int j = 0; j < S2P; ++j) seg2_issue(j);
