@@ -127,21 +127,3 @@ extern "C" int mcg_pool_stats(int64_t* stats_host /*[4]*/, int trim) {
     stats_host[2] = P.n_driver_allocs; stats_host[3] = P.n_pool_hits;
     return MCG_OK;
 }
-
-// One non-blocking "setup" stream per device for the uploads and memsets of plan creation.  They used to go through the
-// legacy stream (hipMemcpy / hipMemset): that orders with every blocking stream of the process and, on ROCm 7.2, FAILS while any
-// other thread of the process is inside a stream capture - even a thread-local one (round 6,
-// test_plans_destroyed_on_another_thread_while_this_one_captures_graphs: "table upload failed" in 23 of 25 runs).  A stream of its
-// own has neither coupling; the creator waits for it before it hands the plan out.
-hipStream_t mcg_setup_stream() {
-    static hipStream_t streams[64];
-    static bool made[64];
-    const int dev = cur_dev();
-    std::lock_guard<std::mutex> lock(g_mu);
-    if (!made[dev]) {
-        if (hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); streams[dev] = nullptr; }
-        made[dev] = true;
-    }
-    return streams[dev];
-}
-

@@ -185,7 +185,6 @@ struct mcg_plan_mark_guard {              // marks at scope exit, whatever the r
 int mcg_dev_alloc(size_t bytes, void** out);
 void mcg_dev_free(void* p);
 void mcg_dev_trim();
-hipStream_t mcg_setup_stream();          // per-device non-blocking stream for plan uploads / memsets (nullptr: fall back to the legacy stream)
 
 // small device-memory helpers shared by the model and plan builders
 int mcg_upload_f(const std::vector<float>& v, float** d);

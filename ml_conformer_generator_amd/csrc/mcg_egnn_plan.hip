@@ -12,7 +12,8 @@ int mcg_plan_B(const mcg_plan* p) { return p->B; }
 int mcg_plan_N(const mcg_plan* p) { return p->N; }
 const int* mcg_plan_n_nodes(const mcg_plan* p) { return p->n_nodes; }
 
-static int plan_create_single(int B, int N, const int32_t* n_nodes_host, const mcg_plan_opts* opts, mcg_plan** out) {
+// `ss`: the non-blocking stream the uploads and the workspace memset go through (the top-level plan's capture stream; idle at this point)
+static int plan_create_single(int B, int N, const int32_t* n_nodes_host, const mcg_plan_opts* opts, mcg_plan** out, hipStream_t ss) {
     if (B < 1 || N < 1 || !n_nodes_host || !out) {
         mcg_set_error("mcg_plan_create: bad arguments");
         return MCG_ERR_ARG;
@@ -76,8 +77,10 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, const m
     void* tab_block = nullptr;
     if (int e = mcg_dev_alloc(tab_bytes, &tab_block)) { delete p; return e; }
     p->allocs.push_back(tab_block);
-    // (on the setup stream, not the legacy stream: mcg_devmem.hip - plan creation must work while another thread captures a graph)
-    hipStream_t ss = mcg_setup_stream();
+    // (NOT through the legacy stream - hipMemcpy / hipMemset: on ROCm 7.2 those FAIL while any other thread of the process is inside a
+    //  stream capture, thread-local or not (round 6, test_plans_destroyed_on_another_thread_while_this_one_captures_graphs: 23 of 25
+    //  runs) - but through the plan's own non-blocking capture stream.  Not a process-wide setup stream either: a persistent extra
+    //  stream shifts the process's streams over the hardware queues and cost two rank processes sharing one GPU 15 %.)
     if (hipMemcpyAsync(tab_block, stage.data(), tab_bytes, hipMemcpyHostToDevice, ss) != hipSuccess || hipStreamSynchronize(ss) != hipSuccess) {
         (void)hipGetLastError();
         mcg_set_error("mcg_plan_create: table upload failed");
@@ -166,7 +169,10 @@ int mcg_plan_create_ex(int B, int N, const int32_t* n_nodes_host, const mcg_plan
         for (int k = 0; k < 5; ++k)
             if (opts->reserved[k] != 0) { mcg_set_error("mcg_plan_create_ex: mcg_plan_opts.reserved must be zero"); return MCG_ERR_ARG; }
     mcg_plan* p = nullptr;
-    if (int e = plan_create_single(B, N, n_nodes_host, opts, &p)) return e;
+    hipStream_t cs = nullptr;             // the plan's capture stream, created first: plan creation uploads through it
+    MCG_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    if (int e = plan_create_single(B, N, n_nodes_host, opts, &p, cs)) { (void)hipStreamDestroy(cs); return e; }
+    p->cap_stream = cs;
     if (hipGetDevice(&p->dev) != hipSuccess) { (void)hipGetLastError(); p->dev = -1; }
     if (hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); p->ev_done = nullptr; }
     if (int e = plan_finish(p, B, N, n_nodes_host, opts)) {
@@ -182,7 +188,6 @@ static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, c
     const int n_ranges = opts ? opts->n_ranges : 0;
     if (int e = mcg_dev_alloc((size_t)B * sizeof(float), (void**)&p->t_buf)) return e;
     p->allocs.push_back(p->t_buf);
-    MCG_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
     // Split the batch into `parts` molecule ranges of ~equal edge count, one HIP stream each: the launch-bound node GEMMs
     // of one range run under another range's edge kernel, and the ramps / tails of the edge kernels overlap.
     // Exact-fp32 plans (16-row tiles), measured per denoiser call (tools/bench_kernels.py --ranges; W = workgroup-equivalents =
@@ -212,7 +217,7 @@ static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, c
     for (size_t k = 0; k + 1 < cuts.size(); ++k) {
         const int b0 = cuts[k], b1 = cuts[k + 1];
         mcg_plan* sub = nullptr;
-        if (int e = plan_create_single(b1 - b0, N, n_nodes_host + b0, opts, &sub)) return e;
+        if (int e = plan_create_single(b1 - b0, N, n_nodes_host + b0, opts, &sub, p->cap_stream)) return e;
         sub->is_sub = true;            // destroyed with its parent, which synchronises the device once for all of them
         p->subs.push_back(sub);
         p->sub_b0.push_back(b0);
