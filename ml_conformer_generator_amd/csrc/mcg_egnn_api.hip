@@ -308,7 +308,7 @@ int run_gcl(const mcg_egnn* m, mcg_plan* pl, int layer, hipStream_t s, bool keep
     // (mcg_node_fused.h) where the three launches would all be the LDS-staged 9-wave kernel; bit-identical h and Pab
     // (from MCG_NF_MIN_ROWBLOCKS row blocks on: ms per denoiser call, three launches -> one, 27-atom molecules, profiles/round6_probes.txt:
     //  4 .. 16 molecules 1.08 -> 1.11, 32 (27 row blocks) 1.29 -> 1.29, 48 (41) 1.70 -> 1.63, 64 1.72 -> 1.64, 128 2.48 -> 2.35, 256 ragged 4.18 -> 3.89)
-    const bool fused = pgather && pl->pspan <= 2 && m->node_fused != 1 && m->gemm_bf16_lds != 1 && Nl.w3_Bp16 && Nl.w4_Bp16 &&
+    const bool fused = pgather && pl->MT == 4 && pl->pspan <= 2 && m->node_fused != 1 && m->gemm_bf16_lds != 1 && Nl.w3_Bp16 && Nl.w4_Bp16 &&
                        (m->node_fused == 2 || (M + 31) / 32 >= MCG_NF_MIN_ROWBLOCKS);
     if (pl->pab_ready) {
         pl->pab_ready = false;                                   // this layer's projections came out of the previous layer's fused launch
