@@ -13,7 +13,9 @@ int mcg_plan_N(const mcg_plan* p) { return p->N; }
 const int* mcg_plan_n_nodes(const mcg_plan* p) { return p->n_nodes; }
 
 // `ss`: the non-blocking stream the uploads and the workspace memset go through (the top-level plan's capture stream; idle at this point)
-static int plan_create_single(int B, int N, const int32_t* n_nodes_host, const mcg_plan_opts* opts, mcg_plan** out, hipStream_t ss) {
+// (`*ss_io` null: the stream is created HERE, behind the host-side checks - argument and size errors are reported without touching the
+//  device - and handed back; the caller owns it from then on, also when this function fails later)
+static int plan_create_single(int B, int N, const int32_t* n_nodes_host, const mcg_plan_opts* opts, mcg_plan** out, hipStream_t* ss_io) {
     if (B < 1 || N < 1 || !n_nodes_host || !out) {
         mcg_set_error("mcg_plan_create: bad arguments");
         return MCG_ERR_ARG;
@@ -23,6 +25,8 @@ static int plan_create_single(int B, int N, const int32_t* n_nodes_host, const m
     (void)hipGetLastError();
     McgPlanHost H;
     if (int e = mcg_plan_build_host(B, N, n_nodes_host, opts, cus, H)) return e;
+    if (!*ss_io) MCG_HIP(hipStreamCreateWithFlags(ss_io, hipStreamNonBlocking));
+    const hipStream_t ss = *ss_io;
     mcg_plan* p = new mcg_plan();
     p->B = H.B; p->N = H.N; p->M = H.M; p->n_rows = H.n_rows; p->n_mtiles = H.n_mtiles; p->MT = H.MT; p->n_waves = H.n_waves;
     p->n_pslots = H.n_pslots; p->wgc = H.wgc;
@@ -169,9 +173,8 @@ int mcg_plan_create_ex(int B, int N, const int32_t* n_nodes_host, const mcg_plan
         for (int k = 0; k < 5; ++k)
             if (opts->reserved[k] != 0) { mcg_set_error("mcg_plan_create_ex: mcg_plan_opts.reserved must be zero"); return MCG_ERR_ARG; }
     mcg_plan* p = nullptr;
-    hipStream_t cs = nullptr;             // the plan's capture stream, created first: plan creation uploads through it
-    MCG_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-    if (int e = plan_create_single(B, N, n_nodes_host, opts, &p, cs)) { (void)hipStreamDestroy(cs); return e; }
+    hipStream_t cs = nullptr;             // the plan's capture stream: created inside, plan creation uploads through it
+    if (int e = plan_create_single(B, N, n_nodes_host, opts, &p, &cs)) { if (cs) (void)hipStreamDestroy(cs); return e; }
     p->cap_stream = cs;
     if (hipGetDevice(&p->dev) != hipSuccess) { (void)hipGetLastError(); p->dev = -1; }
     if (hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); p->ev_done = nullptr; }
@@ -217,7 +220,7 @@ static int plan_finish(mcg_plan* p, int B, int N, const int32_t* n_nodes_host, c
     for (size_t k = 0; k + 1 < cuts.size(); ++k) {
         const int b0 = cuts[k], b1 = cuts[k + 1];
         mcg_plan* sub = nullptr;
-        if (int e = plan_create_single(b1 - b0, N, n_nodes_host + b0, opts, &sub, p->cap_stream)) return e;
+        if (int e = plan_create_single(b1 - b0, N, n_nodes_host + b0, opts, &sub, &p->cap_stream)) return e;
         sub->is_sub = true;            // destroyed with its parent, which synchronises the device once for all of them
         p->subs.push_back(sub);
         p->sub_b0.push_back(b0);
