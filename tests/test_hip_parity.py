@@ -754,14 +754,15 @@ def test_bf16_mode_at_the_judged_step_counts_vs_reference_and_emulation():
 
 
 def test_config5_share_ragged256_bf16_inpaint_properties():
-    """One GPU's share of BASELINE configs[4] at full width: 256 ragged molecules (15..39 atoms), bf16 operands,
-    fixed 8-atom fragment, resample_steps = 1, short schedule (T = 20 -> 41 denoiser calls; the oracle would need
-    ~10 min per call at this size).  Size-independent properties: finite outputs, one-hot atom types with the
-    reference's 7-of-8 argmax, padded slots exactly zero, bit-identical reruns (no atomics anywhere), 64-row units in use."""
+    """One GPU's share of BASELINE configs[4] at full width AND full length (round 6: T = 250 -> 501 denoiser calls, ~2 s per
+    run; T = 20 until round 5): 256 ragged molecules (15..39 atoms), bf16 operands, fixed 8-atom fragment, resample_steps = 1
+    (the oracle would need ~10 min per call at this size).  Size-independent properties: finite outputs, one-hot atom types
+    with the reference's 7-of-8 argmax, padded slots exactly zero, bit-identical reruns (no atomics anywhere), 64-row units
+    and the fused node launch in use."""
     from ml_conformer_generator_amd import MLConformerGenerator
     from ml_conformer_generator_amd import weights as W
     from ml_conformer_generator_amd.synthetic import DUMMY_CONTEXT
-    gen = MLConformerGenerator(diffusion_steps=20, device=DEV, edm_weights=W.synth_edm_state_dict(1234, weight_gain=0.3),
+    gen = MLConformerGenerator(diffusion_steps=250, device=DEV, edm_weights=W.synth_edm_state_dict(1234, weight_gain=0.3),
                                adj_mat_seer_weights=W.synth_adj_mat_seer_state_dict(4321), compute_dtype="bf16")
     fx = torch.tensor([[1.25 * i, 0.72 * (i % 2), 0.3 * ((i // 2) % 2)] for i in range(8)], dtype=torch.float32)
     frag = (fx - fx.mean(0), [6, 6, 6, 6, 6, 6, 17, 17])
@@ -771,7 +772,11 @@ def test_config5_share_ragged256_bf16_inpaint_properties():
         torch.manual_seed(3)
         return gen.edm_tensors(ctx, n_samples=256, min_n_nodes=15, max_n_nodes=39, resample_steps=1, fixed_fragment=frag,
                                inertial_fragment_matching=False, blend_power=3)
+    from ml_conformer_generator_amd import _lib
+    c = np.zeros(32, dtype=np.int64)
+    _lib.check(_lib.lib().mcg_debug_gemm_launches(c.ctypes.data, 1), "mcg_debug_gemm_launches")        # reset
     x1, h1, nm1 = run()
+    _lib.check(_lib.lib().mcg_debug_gemm_launches(c.ctypes.data, 1), "mcg_debug_gemm_launches")        # what the first call's capture issued
     x2, h2, nm2 = run()
     assert torch.equal(x1, x2) and torch.equal(h1, h2)
     assert bool(torch.isfinite(x1).all())
@@ -779,6 +784,7 @@ def test_config5_share_ragged256_bf16_inpaint_properties():
     assert float(h1[:, :, 7].abs().max()) == 0.0                     # the reference's 7-of-8 argmax: Br is never emitted
     assert float((x1 * (1 - nm1)).abs().max()) == 0.0 and float((h1 * (1 - nm1)).abs().max()) == 0.0
     assert gen.generative_model.dynamics.plan(nm1.sum(1).reshape(-1).to(torch.int32).cpu(), 39).edge_mt == 4
+    assert int(c.reshape(4, 8)[1][6]) >= 36        # the two molecule ranges' captures each issued 18 fused node launches
 
 
 @pytest.mark.parametrize("mode", ["f32", "f32x6"])
